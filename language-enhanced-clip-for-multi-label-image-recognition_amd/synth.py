@@ -1,0 +1,279 @@
+"""Deterministic synthetic data: counter-based, integer-hash generator.
+
+There are no pretrained CLIP weights offline, so every parity
+test, the smoke test and the benchmark run on weights and images produced here.
+The generator is *counter based* (element ``i`` of tensor ``name`` depends only on
+``(seed, name, i)``) and uses only 64-bit integer arithmetic plus one exact fp64
+multiply, so the container that wrote the golden fixtures and the GPU box that
+checks them see identical bits.
+
+Normal variates are Irwin-Hall(8): the centred sum of eight 16-bit uniform
+integers (two splitmix64 words per element), scaled to unit variance.
+
+State-dict key names and shapes are those ``build_model`` consumes
+(reference ``project/my_code/clip/model.py:435-472``); the two named
+distributions are
+
+* ``"default"`` - the reference initialisers (``model.py:249-257, 335-362`` and the
+  PyTorch defaults for the remaining Linear/MHA/LayerNorm tensors); a random CLIP
+  at these scales collapses (image-image cosine 0.98) - plumbing case;
+* ``"cond"``    - input-sensitive *and* well-conditioned scales: SURVEY.md §8d's proposal
+  (in_proj 3/sqrt(d), biases 0.5) is chaotic - measured here, bf16 rounding of GEMM inputs
+  moves its cosine logits by 2.4e-2 rms against a per-class spread of 3.4e-2 (top-1 agreement
+  0.44) - so the attention/MLP input scales are 2/sqrt(d) with 0.3 biases instead: image-image
+  cosine 0.73, 9 distinct argmaxes in 16 images, per-class logit spread 2.0e-2, bf16 error
+  1.5e-3 rms (fp16 1.4e-4), top-1 agreement 1.00 (DESIGN.md "Synthetic weights").  LayerNorm
+  affine terms are perturbed so gamma/beta paths are exercised.
+
+All weights are rounded to fp16-representable values, like a released checkpoint
+after ``convert_weights`` + ``.float()`` (``model.py:411-432``, ``clip.py:128-129``).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, asdict
+from typing import Dict, Optional
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GOLD = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
+_IH_SCALE = 1.0 / (65536.0 * math.sqrt(8.0 / 12.0))
+_CHUNK = 1 << 22
+
+
+@dataclass(frozen=True)
+class ClipArch:
+    """Shape parameters ``build_model`` infers from a state-dict (model.py:439-458)."""
+    embed_dim: int = 512
+    image_resolution: int = 224
+    vision_layers: int = 12
+    vision_width: int = 768
+    vision_patch_size: int = 16
+    context_length: int = 77
+    vocab_size: int = 49408
+    transformer_width: int = 512
+    transformer_heads: int = 8
+    transformer_layers: int = 12
+
+    @property
+    def vision_heads(self) -> int:
+        return self.vision_width // 64
+
+    @property
+    def grid(self) -> int:
+        return self.image_resolution // self.vision_patch_size
+
+    @property
+    def vision_tokens(self) -> int:
+        return self.grid * self.grid + 1
+
+    def to_dict(self):
+        return asdict(self)
+
+
+VIT_B16 = ClipArch()
+VIT_L14_336 = ClipArch(embed_dim=768, image_resolution=336, vision_layers=24, vision_width=1024,
+                       vision_patch_size=14, transformer_width=768, transformer_heads=12)
+# small shapes for per-stage parity fixtures: 2 heads per tower, 17 / 77 tokens
+TINY = ClipArch(embed_dim=64, image_resolution=32, vision_layers=2, vision_width=128,
+                vision_patch_size=8, context_length=77, vocab_size=49408,
+                transformer_width=128, transformer_heads=2, transformer_layers=2)
+
+ARCHS = {"ViT-B/16": VIT_B16, "ViT-L/14@336px": VIT_L14_336, "tiny": TINY}
+
+
+def fnv1a64(text: str) -> int:
+    h = 0xCBF29CE484222325
+    for b in text.encode("utf-8"):
+        h ^= b
+        h = (h * 0x100000001B3) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    z = x + _GOLD
+    z = (z ^ (z >> np.uint64(30))) * _C1
+    z = (z ^ (z >> np.uint64(27))) * _C2
+    return z ^ (z >> np.uint64(31))
+
+
+def _key(seed: int, name: str) -> np.uint64:
+    k = fnv1a64(name) ^ ((seed * 0xD1342543DE82EF95 + 0x2545F4914F6CDD1D) & 0xFFFFFFFFFFFFFFFF)
+    return np.uint64(k)
+
+
+def _words(key: np.uint64, start: int, count: int) -> np.ndarray:
+    idx = np.arange(start, start + count, dtype=np.uint64)
+    return _splitmix64(key + idx)
+
+
+def uniform_u16x8_sum(seed: int, name: str, n: int) -> np.ndarray:
+    """int64[n]: sum of eight 16-bit uniform chunks per element (Irwin-Hall numerator)."""
+    out = np.empty(n, dtype=np.int64)
+    key = _key(seed, name)
+    m16 = np.uint64(0xFFFF)
+    with np.errstate(over="ignore"):
+        for s in range(0, n, _CHUNK):
+            c = min(_CHUNK, n - s)
+            w = _words(key, 2 * s, 2 * c)
+            acc = np.zeros(2 * c, dtype=np.uint64)
+            for sh in (0, 16, 32, 48):
+                acc += (w >> np.uint64(sh)) & m16
+            out[s:s + c] = (acc[0::2] + acc[1::2]).astype(np.int64)
+    return out
+
+
+def normal(seed: int, name: str, shape, std: float = 1.0, mean: float = 0.0) -> np.ndarray:
+    """float32 ~N(mean, std^2) (Irwin-Hall(8) approximation, |z| <= 4.9)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    s = uniform_u16x8_sum(seed, name, n)
+    z = (s.astype(np.float64) - 8.0 * 32767.5) * _IH_SCALE
+    return (z * std + mean).astype(np.float32).reshape(shape)
+
+
+def uniform(seed: int, name: str, shape, lo: float, hi: float) -> np.ndarray:
+    """float32 ~U[lo, hi) from the top 53 bits of one hash word per element."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    out = np.empty(n, dtype=np.float64)
+    key = _key(seed, name + "#u")
+    with np.errstate(over="ignore"):
+        for s in range(0, n, _CHUNK):
+            c = min(_CHUNK, n - s)
+            w = _words(key, s, c)
+            out[s:s + c] = (w >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return (lo + (hi - lo) * out).astype(np.float32).reshape(shape)
+
+
+def round_fp16(a: np.ndarray) -> np.ndarray:
+    return a.astype(np.float16).astype(np.float32)
+
+
+def _block_specs(prefix: str, d: int, layers: int, dist: str, text: bool) -> Dict[str, tuple]:
+    """name -> (shape, kind, param).  kind: 'n' normal std, 'u' uniform bound, 'c' constant,
+    'g' gamma-like 1+N(0,s), following model.py:352-359 (text tower) and nn defaults."""
+    sp: Dict[str, tuple] = {}
+    for i in range(layers):
+        p = f"{prefix}resblocks.{i}."
+        if dist == "cond":
+            sp[p + "attn.in_proj_weight"] = ((3 * d, d), "n", 2.0 * d ** -0.5)
+            sp[p + "attn.in_proj_bias"] = ((3 * d,), "n", 0.3)
+            sp[p + "attn.out_proj.weight"] = ((d, d), "n", d ** -0.5)
+            sp[p + "attn.out_proj.bias"] = ((d,), "n", 0.05)
+            sp[p + "mlp.c_fc.weight"] = ((4 * d, d), "n", 2.0 * d ** -0.5)
+            sp[p + "mlp.c_fc.bias"] = ((4 * d,), "n", 0.3)
+            sp[p + "mlp.c_proj.weight"] = ((d, 4 * d), "n", (4 * d) ** -0.5)
+            sp[p + "mlp.c_proj.bias"] = ((d,), "n", 0.05)
+            for ln in ("ln_1", "ln_2"):
+                sp[p + ln + ".weight"] = ((d,), "g", 0.1)
+                sp[p + ln + ".bias"] = ((d,), "n", 0.1)
+        else:
+            if text:  # CLIP.initialize_parameters, model.py:352-359
+                attn_std, proj_std, fc_std = d ** -0.5, d ** -0.5 * (2 * layers) ** -0.5, (2 * d) ** -0.5
+                sp[p + "attn.in_proj_weight"] = ((3 * d, d), "n", attn_std)
+                sp[p + "attn.out_proj.weight"] = ((d, d), "n", proj_std)
+                sp[p + "mlp.c_fc.weight"] = ((4 * d, d), "n", fc_std)
+                sp[p + "mlp.c_proj.weight"] = ((d, 4 * d), "n", proj_std)
+            else:  # nn.MultiheadAttention xavier_uniform / nn.Linear kaiming_uniform(a=sqrt5)
+                sp[p + "attn.in_proj_weight"] = ((3 * d, d), "u", math.sqrt(6.0 / (d + 3 * d)))
+                sp[p + "attn.out_proj.weight"] = ((d, d), "u", d ** -0.5)
+                sp[p + "mlp.c_fc.weight"] = ((4 * d, d), "u", d ** -0.5)
+                sp[p + "mlp.c_proj.weight"] = ((d, 4 * d), "u", (4 * d) ** -0.5)
+            sp[p + "attn.in_proj_bias"] = ((3 * d,), "c", 0.0)
+            sp[p + "attn.out_proj.bias"] = ((d,), "c", 0.0)
+            sp[p + "mlp.c_fc.bias"] = ((4 * d,), "u", d ** -0.5)
+            sp[p + "mlp.c_proj.bias"] = ((d,), "u", (4 * d) ** -0.5)
+            for ln in ("ln_1", "ln_2"):
+                sp[p + ln + ".weight"] = ((d,), "c", 1.0)
+                sp[p + ln + ".bias"] = ((d,), "c", 0.0)
+    return sp
+
+
+def state_dict_specs(arch: ClipArch, dist: str = "cond", towers: str = "both") -> Dict[str, tuple]:
+    assert dist in ("cond", "default") and towers in ("both", "visual", "text")
+    sp: Dict[str, tuple] = {}
+    w, p = arch.vision_width, arch.vision_patch_size
+    if towers in ("both", "visual"):
+        sc = w ** -0.5
+        fan_in = 3 * p * p
+        sp["visual.conv1.weight"] = ((w, 3, p, p), "u", fan_in ** -0.5)  # Conv2d default, no bias (model.py:247)
+        sp["visual.class_embedding"] = ((w,), "n", sc)
+        sp["visual.positional_embedding"] = ((arch.vision_tokens, w), "n", sc)
+        lnk = ("g", 0.1, "n", 0.1) if dist == "cond" else ("c", 1.0, "c", 0.0)
+        for ln in ("visual.ln_pre", "visual.ln_post"):
+            sp[ln + ".weight"] = ((w,), lnk[0], lnk[1])
+            sp[ln + ".bias"] = ((w,), lnk[2], lnk[3])
+        sp.update(_block_specs("visual.transformer.", w, arch.vision_layers, dist, text=False))
+        sp["visual.proj"] = ((w, arch.embed_dim), "n", sc)
+    if towers in ("both", "text"):
+        d = arch.transformer_width
+        sp["token_embedding.weight"] = ((arch.vocab_size, d), "n", 1.0 if dist == "cond" else 0.02)
+        sp["positional_embedding"] = ((arch.context_length, d), "n", 0.01)
+        sp.update(_block_specs("transformer.", d, arch.transformer_layers, dist, text=True))
+        lnk = ("g", 0.1, "n", 0.1) if dist == "cond" else ("c", 1.0, "c", 0.0)
+        sp["ln_final.weight"] = ((d,), lnk[0], lnk[1])
+        sp["ln_final.bias"] = ((d,), lnk[2], lnk[3])
+        sp["text_projection"] = ((d, arch.embed_dim), "n", d ** -0.5)
+    sp["logit_scale"] = ((), "c", math.log(1.0 / 0.07))  # model.py:331
+    return sp
+
+
+def make_tensor(seed: int, name: str, spec: tuple) -> np.ndarray:
+    shape, kind, par = spec
+    if kind == "n":
+        a = normal(seed, name, shape, std=par)
+    elif kind == "g":
+        a = normal(seed, name, shape, std=par, mean=1.0)
+    elif kind == "u":
+        a = uniform(seed, name, shape, -par, par)
+    else:
+        a = np.full(shape, par, dtype=np.float32)
+    return round_fp16(a)
+
+
+def make_state_dict(arch: ClipArch, seed: int = 0, dist: str = "cond", towers: str = "both",
+                    as_torch: bool = True):
+    """Synthetic OpenAI-CLIP-shaped state-dict (fp32 tensors holding fp16-representable values)."""
+    sd = {}
+    for name, spec in state_dict_specs(arch, dist, towers).items():
+        a = make_tensor(seed, name, spec)
+        if as_torch:
+            import torch
+            sd[name] = torch.from_numpy(np.ascontiguousarray(a))
+        else:
+            sd[name] = a
+    return sd
+
+
+def make_images(batch: int, resolution: int = 224, seed: int = 1234, start: int = 0) -> np.ndarray:
+    """float32 N(0,1) images [batch,3,R,R] (post-``Normalize`` statistics, clip.py:77).
+    Image ``b`` depends only on ``(seed, start+b)`` so shards of a global batch agree."""
+    per = 3 * resolution * resolution
+    out = np.empty((batch, 3, resolution, resolution), dtype=np.float32)
+    for b in range(batch):
+        out[b] = normal(seed, f"image.{start + b}", (3, resolution, resolution))
+    return out
+
+
+def make_ctx(n_ctx: int, dim: int, seed: int = 0, name: str = "ctx", n_cls: Optional[int] = None) -> np.ndarray:
+    """Learnable-context init N(0, 0.02^2) (Caption_distill_double.py:128-134)."""
+    shape = (n_ctx, dim) if n_cls is None else (n_cls, n_ctx, dim)
+    return normal(seed, f"prompt_learner.{name}", shape, std=0.02)
+
+
+def gumbel(seed: int, name: str, shape) -> np.ndarray:
+    u = uniform(seed, name, shape, 0.0, 1.0).astype(np.float64)
+    u = np.clip(u, 1e-12, 1.0 - 1e-12)
+    return (-np.log(-np.log(u))).astype(np.float32)
+
+
+def make_labels_from_logits(z: np.ndarray, seed: int = 7, topk: int = 3, noise: float = 0.5) -> np.ndarray:
+    """Synthetic multi-hot targets from oracle-side fp32 logits:
+    y[b,c]=1 iff z[b,c] + noise*std(z)*g[b,c] is in the per-image top-k, g ~ Gumbel."""
+    z = np.asarray(z, dtype=np.float64)
+    g = gumbel(seed, "labels", z.shape).astype(np.float64)
+    s = z + noise * z.std() * g
+    kth = np.sort(s, axis=1)[:, -topk][:, None]
+    return (s >= kth).astype(np.int64)

@@ -1,0 +1,220 @@
+"""CPU oracle: fp32 restatement of the reference's CLIP scoring path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing in the product package imports this module;
+only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may (the product path fails loudly when the HIP library is missing).
+
+Every function restates, in plain ``torch`` CPU tensor algebra on a state-dict
+(no ``nn.Module``), the arithmetic of one piece of the reference and cites it.
+Pinned (parity is NOT unpinned): ``oracle/make_golden.py`` imports the reference's
+own ``project/my_code/clip/model.py`` in the build container, loads the same
+synthetic state-dicts, and writes its outputs to ``tests/golden/``;
+``tests/test_oracle_golden.py`` holds this file to those vectors (<=2e-5 abs,
+label indices exact) on every run, with or without ``/root/reference``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+
+
+def layer_norm(x: Tensor, w: Tensor, b: Tensor, eps: float = 1e-5) -> Tensor:
+    """model.py:193-199 - LayerNorm evaluated in fp32 (eps = nn.LayerNorm default 1e-5)."""
+    xf = x.float()
+    mu = xf.mean(dim=-1, keepdim=True)
+    var = ((xf - mu) ** 2).mean(dim=-1, keepdim=True)
+    return ((xf - mu) * torch.rsqrt(var + eps) * w.float() + b.float()).to(x.dtype)
+
+
+def quick_gelu(x: Tensor) -> Tensor:
+    """model.py:202-204 - x * sigmoid(1.702 x)."""
+    return x * torch.sigmoid(1.702 * x)
+
+
+def causal_mask(n: int) -> Tensor:
+    """model.py:364-370 - additive mask, -inf strictly above the diagonal."""
+    m = torch.full((n, n), float("-inf"))
+    return torch.triu(m, diagonal=1)
+
+
+def multi_head_attention(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int,
+                         mask: Optional[Tensor], taps: Optional[dict] = None) -> Tensor:
+    """model.py:211,221-223 (nn.MultiheadAttention, packed in-proj, q|k|v order).
+    x: [N, T, d] (batch-major; the reference's LND layout is a pure permutation)."""
+    n, t, d = x.shape
+    dh = d // heads
+    qkv = x @ sd[p + "attn.in_proj_weight"].t() + sd[p + "attn.in_proj_bias"]
+    q, k, v = qkv.split(d, dim=-1)
+    q = q.reshape(n, t, heads, dh).transpose(1, 2)
+    k = k.reshape(n, t, heads, dh).transpose(1, 2)
+    v = v.reshape(n, t, heads, dh).transpose(1, 2)
+    s = (q @ k.transpose(-1, -2)) * (1.0 / math.sqrt(dh))
+    if mask is not None:
+        s = s + mask
+    pr = torch.softmax(s, dim=-1)
+    o = (pr @ v).transpose(1, 2).reshape(n, t, d)
+    if taps is not None:
+        taps["qkv"] = qkv
+        taps["attn_ctx"] = o
+    return o @ sd[p + "attn.out_proj.weight"].t() + sd[p + "attn.out_proj.bias"]
+
+
+def residual_block(x: Tensor, sd: Dict[str, Tensor], p: str, heads: int, mask: Optional[Tensor],
+                   taps: Optional[dict] = None) -> Tensor:
+    """model.py:225-228 - x += attn(ln_1 x); x += c_proj(QuickGELU(c_fc(ln_2 x)))."""
+    h = layer_norm(x, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"])
+    if taps is not None:
+        taps["ln_1"] = h
+    x = x + multi_head_attention(h, sd, p, heads, mask, taps)
+    if taps is not None:
+        taps["after_attn"] = x
+    h = layer_norm(x, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"])
+    u = quick_gelu(h @ sd[p + "mlp.c_fc.weight"].t() + sd[p + "mlp.c_fc.bias"])
+    if taps is not None:
+        taps["ln_2"] = h
+        taps["gelu"] = u
+    x = x + (u @ sd[p + "mlp.c_proj.weight"].t() + sd[p + "mlp.c_proj.bias"])
+    if taps is not None:
+        taps["out"] = x
+    return x
+
+
+def _n_layers(sd: Dict[str, Tensor], prefix: str) -> int:
+    return len([k for k in sd if k.startswith(prefix) and k.endswith(".attn.in_proj_weight")])
+
+
+def patch_embed(image: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """model.py:260-264 - stride-p conv without bias, flatten, prepend class token, add pos-emb."""
+    w = sd["visual.conv1.weight"]
+    width, _, p, _ = w.shape
+    b, c, hh, ww = image.shape
+    g = hh // p
+    # conv with kernel == stride is a GEMM over non-overlapping patches, k = (c, py, px)
+    patches = image.reshape(b, c, g, p, g, p).permute(0, 2, 4, 1, 3, 5).reshape(b, g * g, c * p * p)
+    x = patches @ w.reshape(width, -1).t()
+    cls = sd["visual.class_embedding"].expand(b, 1, width)
+    return torch.cat([cls, x], dim=1) + sd["visual.positional_embedding"]
+
+
+def encode_image(image: Tensor, sd: Dict[str, Tensor], taps: Optional[dict] = None) -> Tensor:
+    """VisionTransformer.forward, model.py:259-276 (CLIP.encode_image, 376-377)."""
+    image = image.float()
+    width = sd["visual.conv1.weight"].shape[0]
+    heads = width // 64
+    x = patch_embed(image, sd)
+    if taps is not None:
+        taps["embed"] = x
+    x = layer_norm(x, sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
+    if taps is not None:
+        taps["ln_pre"] = x
+    for i in range(_n_layers(sd, "visual.transformer.")):
+        bt = {} if taps is not None else None
+        x = residual_block(x, sd, f"visual.transformer.resblocks.{i}.", heads, None, bt)
+        if taps is not None:
+            taps[f"block{i}"] = bt
+    x = layer_norm(x[:, 0, :], sd["visual.ln_post.weight"], sd["visual.ln_post.bias"])
+    if taps is not None:
+        taps["ln_post"] = x
+    return x @ sd["visual.proj"]
+
+
+def text_transformer(x: Tensor, sd: Dict[str, Tensor], taps: Optional[dict] = None) -> Tensor:
+    """The shared middle of CLIP.encode_text (model.py:382-387) and TextEncoder.forward
+    (Caption_distill_double.py:86-90): + positional embedding, causal blocks, ln_final."""
+    d = sd["ln_final.weight"].shape[0]
+    heads = d // 64
+    t = x.shape[1]
+    x = x.float() + sd["positional_embedding"][:t]
+    mask = causal_mask(t)
+    for i in range(_n_layers(sd, "transformer.")):
+        bt = {} if taps is not None else None
+        x = residual_block(x, sd, f"transformer.resblocks.{i}.", heads, mask, bt)
+        if taps is not None:
+            taps[f"block{i}"] = bt
+    x = layer_norm(x, sd["ln_final.weight"], sd["ln_final.bias"])
+    if taps is not None:
+        taps["ln_final"] = x
+    return x
+
+
+def text_encoder(prompts: Tensor, tokenized_prompts: Optional[Tensor], sd: Dict[str, Tensor],
+                 if_embedding: bool = True, if_sequence: bool = False,
+                 taps: Optional[dict] = None) -> Tensor:
+    """TextEncoder.forward, Caption_distill_double.py:82-101.  With ``if_embedding=False`` the
+    first argument holds token ids (83-85) and this is CLIP.encode_text (model.py:379-392)."""
+    if not if_embedding:
+        tokenized_prompts = prompts
+        prompts = sd["token_embedding.weight"][prompts]
+    x = text_transformer(prompts, sd, taps)
+    if if_sequence:
+        return x @ sd["text_projection"]
+    eot = tokenized_prompts.argmax(dim=-1)  # EOT has the largest id (model.py:390)
+    return x[torch.arange(x.shape[0]), eot] @ sd["text_projection"]
+
+
+def encode_text(tokens: Tensor, sd: Dict[str, Tensor], taps: Optional[dict] = None) -> Tensor:
+    return text_encoder(tokens, None, sd, if_embedding=False, taps=taps)
+
+
+def prompt_learner_forward(ctx: Tensor, prefix: Tensor, suffix: Tensor) -> Tensor:
+    """PromptLearner.forward, class_token_position == 'end' (Caption_distill_double.py:206-225):
+    expand a generic [n_ctx,d] context over classes and concatenate [SOS | ctx | class.. EOT pad]."""
+    n_cls = prefix.shape[0]
+    if ctx.dim() == 2:
+        ctx = ctx.unsqueeze(0).expand(n_cls, -1, -1)
+    return torch.cat([prefix, ctx, suffix], dim=1)
+
+
+def prompt_buffers(tokenized_prompts: Tensor, sd: Dict[str, Tensor], n_ctx: int):
+    """PromptLearner.__init__, Caption_distill_double.py:177-184 - frozen SOS / class+EOT embeddings."""
+    emb = sd["token_embedding.weight"][tokenized_prompts]
+    return emb[:, :1, :], emb[:, 1 + n_ctx:, :]
+
+
+def l2_normalize(f: Tensor) -> Tensor:
+    """model.py:399-400 - f / ||f||_2, no epsilon."""
+    return f / f.norm(dim=-1, keepdim=True)
+
+
+def cosine_logits(image_features: Tensor, text_features: Tensor, scale: float) -> Tensor:
+    """model.py:399-404 / Caption_distill_double.py:330-335.  Python precedence makes
+    ``scale * img @ txt.t()`` equal ``(scale * img) @ txt.t()``."""
+    return (scale * l2_normalize(image_features)) @ l2_normalize(text_features).t()
+
+
+def clip_forward(image: Tensor, tokens: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """CLIP.forward -> logits_per_image, model.py:394-408 (scale = exp(logit_scale))."""
+    return cosine_logits(encode_image(image, sd), encode_text(tokens, sd), float(sd["logit_scale"].exp()))
+
+
+def custom_clip_forward(image: Tensor, sd: Dict[str, Tensor], ctx: Tensor, prefix: Tensor, suffix: Tensor,
+                        tokenized_prompts: Tensor, scale: float = 4.0) -> Tensor:
+    """CustomCLIP.forward(if_test=True) as intended (Caption_distill_double.py:323-337; the shipped
+    5-way unpack of a 6-tuple at :326 is the bug SURVEY.md notes - only ``prompts`` is used)."""
+    img = encode_image(image, sd)
+    txt = text_encoder(prompt_learner_forward(ctx, prefix, suffix), tokenized_prompts, sd)
+    return cosine_logits(img, txt, scale)
+
+
+def custom_clip_forward_captions(captions: Tensor, sd: Dict[str, Tensor], ctx: Tensor, prefix: Tensor,
+                                 suffix: Tensor, tokenized_prompts: Tensor, scale: float = 4.0) -> Tensor:
+    """CustomCLIP.forward(if_test=False): captions stand in for images (:338-352)."""
+    img = text_encoder(captions, None, sd, if_embedding=False)
+    txt = text_encoder(prompt_learner_forward(ctx, prefix, suffix), tokenized_prompts, sd)
+    return cosine_logits(img, txt, scale)
+
+
+def flatten_taps(taps: dict, prefix: str = "") -> Dict[str, np.ndarray]:
+    out = {}
+    for k, v in taps.items():
+        if isinstance(v, dict):
+            out.update(flatten_taps(v, prefix + k + "."))
+        else:
+            out[prefix + k] = v.detach().cpu().numpy()
+    return out

@@ -1,0 +1,108 @@
+"""The CPU oracle (oracle/*.py) held to vectors produced by the reference's own code
+(tests/golden/*.npz, written by oracle/make_golden.py in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from leclip_amd import synth
+from oracle import clip_oracle as co
+from oracle import metrics_oracle as mo
+
+TOL = 2e-5  # fp32 CPU: oracle vs reference differ only by summation order
+
+
+def _sd(arch, seed, dist):
+    return synth.make_state_dict(arch, seed=seed, dist=dist)
+
+
+def test_generator_guards(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg1.npz"))
+    assert np.array_equal(g["guard.image0_head"], synth.make_images(1, 224, seed=1234)[0, 0, 0, :16])
+    spec = synth.state_dict_specs(synth.VIT_B16, "default")["visual.conv1.weight"]
+    w = synth.make_tensor(0, "visual.conv1.weight", spec).reshape(-1)[:16]
+    assert np.array_equal(g["guard.conv1_head"], w)
+
+
+def test_tiny_per_stage(golden_dir):
+    g = np.load(os.path.join(golden_dir, "tiny_stages.npz"))
+    sd = _sd(synth.TINY, 1, "cond")
+    img, toks = torch.from_numpy(g["images"]), torch.from_numpy(g["tokens"])
+    taps = {}
+    feat = co.encode_image(img, sd, taps)
+    flat = co.flatten_taps(taps)
+    np.testing.assert_allclose(flat["ln_pre"], g["v.ln_pre"], atol=TOL, rtol=0)
+    for i in range(synth.TINY.vision_layers):
+        for mine, ref in (("ln_1", "ln_1"), ("ln_2", "ln_2"), ("gelu", "gelu"), ("out", "out")):
+            np.testing.assert_allclose(flat[f"block{i}.{mine}"], g[f"v.block{i}.{ref}"], atol=3e-4, rtol=3e-4)
+        attn_out = flat[f"block{i}.after_attn"] - (flat["ln_pre"] if i == 0 else flat[f"block{i-1}.out"])
+        np.testing.assert_allclose(attn_out, g[f"v.block{i}.attn_out"], atol=3e-4, rtol=3e-4)
+    np.testing.assert_allclose(flat["ln_post"], g["v.ln_post"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(feat.numpy(), g["v.feat"], atol=TOL, rtol=0)
+    taps = {}
+    tf = co.encode_text(toks, sd, taps)
+    flat = co.flatten_taps(taps)
+    for i in range(synth.TINY.transformer_layers):
+        for k in ("ln_1", "ln_2", "gelu", "out"):
+            np.testing.assert_allclose(flat[f"block{i}.{k}"], g[f"t.block{i}.{k}"], atol=3e-4, rtol=3e-4)
+    np.testing.assert_allclose(flat["ln_final"], g["t.ln_final"], atol=TOL, rtol=0)
+    np.testing.assert_allclose(tf.numpy(), g["t.feat"], atol=TOL, rtol=0)
+    lpi = co.clip_forward(img, toks, sd)
+    np.testing.assert_allclose(lpi.numpy(), g["logits_per_image"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(lpi.t().numpy(), g["logits_per_text"], atol=1e-4, rtol=0)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("dist", ["cond", "default"])
+def test_vitb16_cfg1(golden_dir, dist):
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg1.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    sd = _sd(synth.VIT_B16, 0, dist)
+    img = torch.from_numpy(synth.make_images(8, 224, seed=1234))
+    toks = torch.from_numpy(t["tokens_photo"])
+    fi = co.encode_image(img, sd)
+    ft = co.encode_text(toks, sd)
+    np.testing.assert_allclose(fi.numpy(), g[dist + ".image_features"], atol=1e-4, rtol=1e-4)
+    np.testing.assert_allclose(ft.numpy(), g[dist + ".text_features"], atol=1e-4, rtol=1e-4)
+    lpi = co.cosine_logits(fi, ft, float(sd["logit_scale"].exp()))
+    np.testing.assert_allclose(lpi.numpy(), g[dist + ".logits_clip"], atol=1e-4, rtol=0)
+    assert np.array_equal(torch.topk(lpi, 5, dim=1).indices.numpy(), g[dist + ".top5_clip"])
+    # learnable-prompt branch: PromptLearner concat + TextEncoder + 4.0-scaled cosine logits
+    tctx = torch.from_numpy(t["tokens_ctx16"])
+    ctx = torch.from_numpy(synth.make_ctx(16, 512, seed=0))
+    prefix, suffix = co.prompt_buffers(tctx, sd, 16)
+    txt = co.text_encoder(co.prompt_learner_forward(ctx, prefix, suffix), tctx, sd)
+    np.testing.assert_allclose(txt.numpy(), g[dist + ".text_features_ctx16"], atol=1e-4, rtol=1e-4)
+    lc = co.cosine_logits(fi, txt, 4.0)
+    np.testing.assert_allclose(lc.numpy(), g[dist + ".logits_custom_ctx16"], atol=2e-5, rtol=0)
+    assert np.array_equal(torch.topk(lc, 5, dim=1).indices.numpy(), g[dist + ".top5_custom_ctx16"])
+    np.testing.assert_allclose(co.cosine_logits(fi, ft, 4.0).numpy(), g[dist + ".logits_custom_fixed"],
+                               atol=2e-5, rtol=0)
+    lcap = co.custom_clip_forward_captions(toks[:6], sd, ctx, prefix, suffix, tctx)
+    np.testing.assert_allclose(lcap.numpy(), g[dist + ".logits_custom_captions"], atol=2e-5, rtol=0)
+
+
+def test_prompt_identity_kat(golden_dir):
+    """ctx := token_embedding('x') repeated => prompts == token_embedding(tokens)."""
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    sd = synth.make_state_dict(synth.TINY, seed=1, dist="cond", towers="text")
+    tctx = torch.from_numpy(t["tokens_ctx16"])
+    x_id = int(tctx[0, 1])
+    assert x_id == 343 and bool((tctx[:, 1:17] == x_id).all())
+    ctx = sd["token_embedding.weight"][x_id].expand(16, -1)
+    prefix, suffix = co.prompt_buffers(tctx, sd, 16)
+    assert torch.equal(co.prompt_learner_forward(ctx, prefix, suffix), sd["token_embedding.weight"][tctx])
+
+
+def test_metric_kats(golden_dir):
+    g = np.load(os.path.join(golden_dir, "metrics_kat.npz"))
+    for case in ("random", "ties", "allneg", "single"):
+        tt, pp = g[f"map.{case}.targets"], g[f"map.{case}.preds"]
+        assert mo.mAP(tt, pp) == pytest.approx(float(g[f"map.{case}.value"]), abs=1e-9)
+        ap = np.array([mo.average_precision(pp[:, c], tt[:, c]) for c in range(pp.shape[1])])
+        np.testing.assert_allclose(ap, g[f"map.{case}.ap"], atol=1e-12)
+    yp, yt = g["loss.pred"], g["loss.target"]
+    assert mo.ranking_loss(yp, yt, 1.0, 1.0) == pytest.approx(float(g["loss.ranking"]), rel=1e-5)
+    assert mo.ranking_loss(yp, yt) == pytest.approx(float(g["loss.ranking_s2"]), rel=1e-5)
+    assert mo.norm_logits_bce(yp, yt) == pytest.approx(float(g["loss.bce"]), rel=1e-5)
