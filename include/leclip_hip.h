@@ -1,0 +1,115 @@
+/*
+ * leclip_hip.h - C ABI of the MI355X (gfx950) kernels behind the CLIP multi-label scoring path.
+ *
+ * The reference (JarvisUSTC/Language-Enhanced-CLIP-For-Multi-label-Image-Recognition) is 100 % Python on
+ * PyTorch: it has no FFI for this path, so there is no reference-side native interface to copy.  Each entry
+ * point below therefore names the reference *Python call* whose arithmetic it replaces (file:line under
+ * /root/reference/project/my_code), and INTEGRATION.md shows the ctypes stub a maintainer adds.
+ *
+ * Conventions (every function):
+ *   - plain C, device pointers + explicit shapes / leading dimensions (in ELEMENTS) + dtype enums;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); functions only ENQUEUE work:
+ *     no allocation, no synchronisation, no host<->device copies, safe under stream capture;
+ *   - the caller owns every buffer including workspaces (sizes from the *_workspace_bytes helpers);
+ *   - returns 0 on success, <0 on error (LECLIP_E_*); leclip_strerror() names the code and
+ *     leclip_last_error() gives the per-thread detail string.  Never throws, never aborts;
+ *   - re-entrant; calls on distinct streams may be issued from distinct host threads.
+ *   - fp32 accumulation everywhere; LayerNorm / softmax statistics in fp32.
+ */
+#ifndef LECLIP_HIP_H
+#define LECLIP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LECLIP_ABI_VERSION 1
+
+typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
+typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
+typedef enum { LECLIP_MASK_NONE = 0, LECLIP_MASK_CAUSAL = 1 } leclip_mask;
+
+#define LECLIP_OK 0
+#define LECLIP_E_INVALID (-1)      /* null pointer / non-positive size / bad enum */
+#define LECLIP_E_UNSUPPORTED (-2)  /* shape or dtype combination this build has no kernel for */
+#define LECLIP_E_LAUNCH (-3)       /* hipLaunchKernel reported an error */
+
+int leclip_abi_version(void);
+const char* leclip_strerror(int code);
+const char* leclip_last_error(void);
+/* Name of the device kernel family a GEMM call with these arguments dispatches to (for profiles/tests). */
+const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_dtype ab_dtype);
+
+/* LayerNorm over the last dimension, fp32 statistics, eps inside the rsqrt.
+ * Replaces clip/model.py:193-199 (LayerNorm.forward: F.layer_norm(x.float(), ...).type(orig)).
+ * y[r, :] = (x[r, :] - mean) * rsqrt(var + eps) * gamma + beta;  gamma/beta fp32 [dim].
+ * dim must be a multiple of 64 and <= 4096. */
+int leclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                         int64_t rows, int dim, int64_t ldx, int64_t ldy, float eps,
+                         leclip_dtype x_dtype, leclip_dtype y_dtype, void* stream);
+
+/* Y[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]       (nn.Linear weight layout, K contiguous)
+ * Replaces the F.linear calls of clip/model.py:213-217,223,226-227 (MHA in-proj / out-proj, mlp.c_fc + QuickGELU
+ * (model.py:202-204: x*sigmoid(1.702x)), mlp.c_proj) with the bias, activation and residual add fused.
+ * A and W share ab_dtype (F32: exact-fp32 MFMA path; F16/BF16: 32x32x16 MFMA, fp32 accumulate).
+ * bias: fp32 or NULL.  residual: res_dtype or NULL; may alias Y (in-place residual stream).
+ * Constraints: N % 128 == 0 and K % 64 == 0 (F16/BF16); N % 64 == 0 and K % 32 == 0 (F32). */
+int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias, const void* residual, void* Y,
+                                 int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy,
+                                 leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
+                                 leclip_dtype y_dtype, void* stream);
+
+/* Patch embedding: X[b, 0, :] = class_emb + pos[0];  X[b, 1+p, :] = conv_{k=s=P, no bias}(image)[b, :, p] + pos[1+p].
+ * Replaces clip/model.py:260-264 (conv1, reshape/permute, class-token concat, positional add).
+ * image [B,3,R,R] (img_dtype), conv weight pre-flattened Wp [width, Kp] in w_dtype with Kp = roundup(3*P*P, 64)
+ * (zero padded), class_emb fp32 [width], pos fp32 [T, width], X [B, T, width] in x_dtype, T = (R/P)^2 + 1.
+ * workspace: leclip_patch_embed_workspace_bytes() bytes (the im2col patch matrix in w_dtype). */
+int64_t leclip_patch_embed_workspace_bytes(int64_t B, int R, int P, leclip_dtype w_dtype);
+int leclip_patch_embed_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, void* X,
+                           int64_t B, int R, int P, int width, leclip_dtype img_dtype, leclip_dtype w_dtype,
+                           leclip_dtype x_dtype, void* workspace, void* stream);
+
+/* Multi-head self-attention core on a packed QKV buffer: out = softmax(q k^T * scale + mask) v per (batch, head).
+ * Replaces the scaled-dot-product step inside nn.MultiheadAttention as called at clip/model.py:221-223
+ * (mask: clip/model.py:364-370 additive -inf strictly above the diagonal for the text tower).
+ * qkv [B*T, 3*heads*64] rows = tokens (batch-major), columns q|k|v each heads*64 (in_proj order); out [B*T, heads*64].
+ * head_dim must be 64.  F16/BF16: T <= 224 (fused single-pass MFMA kernel) or any T (streaming kernel); F32: T <= 304. */
+int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
+                         int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale,
+                         leclip_dtype dtype, void* stream);
+
+/* out[i, :] = LayerNorm(x[row_index[i], :]) @ proj        proj [dim, E] row-major (the reference's `x @ proj`)
+ * Replaces clip/model.py:271-274 (ln_post(x[:,0,:]) @ proj) and clip/model.py:388-390 /
+ * trainers/Caption_distill_double.py:90,100 (ln_final(x)[arange, argmax(tokens)] @ text_projection);
+ * LayerNorm is row-wise, so gathering first is the same arithmetic.  out fp32 [n, E]. */
+int leclip_gather_ln_proj_fwd(const void* x, const int64_t* row_index, const float* gamma, const float* beta,
+                              const void* proj, float* out, int64_t n, int dim, int E, int64_t ldx, float eps,
+                              leclip_dtype x_dtype, leclip_dtype proj_dtype, void* stream);
+
+/* logits[b, c] = scale * <img[b]/||img[b]||, txt[c]/||txt[c]||>      (no epsilon in the norms)
+ * Replaces clip/model.py:399-404 and trainers/Caption_distill_double.py:330-335.  fp32 in, fp32 out. */
+int leclip_l2norm_logits_fwd(const float* img, const float* txt, float* logits, int64_t B, int C, int D,
+                             float scale, void* stream);
+
+/* x[n, t, :] = table[tokens[n, t], :] + pos[t, :]       (clip/model.py:380-382; Caption_distill_double.py:83-86)
+ * table / pos fp32; x in x_dtype. */
+int leclip_embed_tokens_fwd(const int64_t* tokens, const float* table, const float* pos, void* x,
+                            int64_t n, int T, int dim, int64_t vocab, leclip_dtype x_dtype, void* stream);
+
+/* x[c, :, :] = cat(prefix[c] (1 row), ctx (n_ctx rows; generic [n_ctx,dim] if ctx_per_class == 0 else [n_cls,n_ctx,dim]),
+ *                  suffix[c] (T-1-n_ctx rows)) + pos      - PromptLearner.forward 'end' layout + TextEncoder's
+ * positional add (trainers/Caption_distill_double.py:206-225, 86).  All inputs fp32; x in x_dtype. */
+int leclip_prompt_assemble_fwd(const float* prefix, const float* ctx, const float* suffix, const float* pos, void* x,
+                               int64_t n_cls, int n_ctx, int T, int dim, int ctx_per_class,
+                               leclip_dtype x_dtype, void* stream);
+
+/* Index of the maximum token id per row (first occurrence), = tokens.argmax(-1) (clip/model.py:390), plus the flat
+ * row n*T + argmax used by leclip_gather_ln_proj_fwd. */
+int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LECLIP_HIP_H */

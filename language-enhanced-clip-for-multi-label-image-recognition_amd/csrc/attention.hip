@@ -1,0 +1,270 @@
+// Fused multi-head attention core for short sequences (ViT-B/16: T = 197, text: T = 77 causal), head_dim 64.
+//
+// attn_rows_kernel<T, NKT>: one 256-thread workgroup per (batch, head); the head's K and V ([T,64] each, read
+// straight out of the packed QKV activation: 128-byte rows) are staged once into LDS and shared by the 4 waves,
+// each of which owns 32-query blocks.  Per block the wave computes S^T = K.Q^T with v_mfma_f32_32x32x16 (keys on
+// the accumulator ROWS, the query on the LANE), so a query's whole score row (NKT*32 keys) sits in two lanes
+// (l, l+32): softmax needs one cross-lane exchange, no LDS, and - since T <= 224 - no online rescaling.
+// The exponentiated accumulators are converted to 16-bit and fed back as the B operand of O^T = V^T.P^T (the
+// "accumulator tile as next MFMA's operand" identity: element j of lane half h is key 16s + 8(j>>2) + 4h + (j&3)),
+// with V^T fragments produced by the transposing LDS read ds_read_b64_tr_b16 from the row-major V image.
+// LDS swizzles: K rows are read with ds_read_b128 (chunk ^= (row>>1)&7), V rows with the tr read (64-B half ^= (row>>1)&1).
+#include "leclip_common.h"
+
+namespace {
+
+struct AttnArgs {
+    const void* qkv;
+    void* out;
+    int T, heads;
+    int64_t ld_qkv, ld_out;
+    float scale_log2e;  // scale * log2(e)
+    int causal;
+};
+
+template <typename T, int NKT>
+__global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    constexpr int TP = NKT * 32;
+    __shared__ __attribute__((aligned(16))) char sK[TP * 128];
+    __shared__ __attribute__((aligned(16))) char sV[TP * 128];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+    const int d_model = a.heads * 64;
+    const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+
+    // ---- stage K and V: 8 threads x 16 B per 128-byte row, 32 rows per pass
+    for (int r = tid >> 3; r < TP; r += 32) {
+        const int c = tid & 7;
+        v8 kv, vv;
+        if (r < a.T) {
+            const T* row = base + (int64_t)r * a.ld_qkv;
+            kv = *(const v8*)(row + d_model + c * 8);
+            vv = *(const v8*)(row + 2 * d_model + c * 8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { kv[i] = (T)0.f; vv[i] = (T)0.f; }
+        }
+        *(v8*)(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
+        *(v8*)(sV + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nqb = (a.T + 31) >> 5;
+    const int li = lane & 15, dgrp = (lane >> 4) & 1;
+    const char* kbase[4];
+    const char* vbase[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kbase[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+    for (int qb = wave; qb < nqb; qb += 4) {
+        const int qi = qb * 32 + fr;
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        // Q fragments (B operand): Q[q][16s + 8h + j]
+        v8 qf[4];
+        {
+            const T* qp = base + (int64_t)qrow * a.ld_qkv + fh * 8;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + s * 16);
+        }
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+            // key row kt*32 + fr: the swizzle term ((row>>1)&7) depends on fr only, so each k-step has one
+            // lane address and the tile index is an immediate offset
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v8 kf = *(const v8*)(kbase[s] + kt * 4096);
+                sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
+            }
+        }
+        // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
+        const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
+                sc[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+        const float mb = mx * a.scale_log2e;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float p = exp2f(sc[kt][r] * a.scale_log2e - mb);  // masked: exp2(-huge) = 0
+                sc[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                v8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    v8 vf;
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        // key = kt*32 + 16*s2 + 8u + 4h + (li>>2), d0 = 32i + 16*dgrp + 4*(li&3); the 64-byte swizzle
+                        // bit ((key>>1)&1) is (li>>3)&1: lane-constant, folded into vbase[i]
+                        const v4 t4 = lds_read_tr16((const T*)(vbase[i] + (kt * 32 + 16 * s2 + 8 * u) * 128));
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vf[4 * u + e] = t4[e];
+                    }
+                    o[i] = mfma_32x32x16(vf, pf, o[i]);
+                }
+            }
+        }
+        // ---- store: lane owns query qi; registers 4g..4g+3 are 4 consecutive d
+        if (qi < a.T) {
+            T* op = (T*)a.out + ((int64_t)b * a.T + qi) * a.ld_out + h * 64;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    v4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
+                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- fp32 validation kernel
+// One workgroup per (batch, head), K and V in LDS as fp32 (rows padded to 65 floats), one query row per wave at
+// a time: lanes own keys for the scores, then own output dimensions for P.V.  T <= 304 (LDS budget).
+constexpr int F32_TMAX = 304;
+
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smf[];
+    float* sK = smf;                       // [T][65]
+    float* sV = smf + (size_t)a.T * 65;    // [T][65]
+    float* sP = sV + (size_t)a.T * 65;     // [4][TPAD]
+    const int TPAD = (a.T + 63) & ~63;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+    const int d_model = a.heads * 64;
+    const float* base = (const float*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+    for (int i = tid; i < a.T * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        sK[r * 65 + c] = base[(int64_t)r * a.ld_qkv + d_model + c];
+        sV[r * 65 + c] = base[(int64_t)r * a.ld_qkv + 2 * d_model + c];
+    }
+    __syncthreads();
+    const float scale = a.scale_log2e * 0.6931471805599453f;
+    float* myP = sP + wave * TPAD;
+    for (int q = wave; q < a.T; q += 4) {
+        const float qd = base[(int64_t)q * a.ld_qkv + lane];   // q[d = lane]
+        const int klimit = a.causal ? q : a.T - 1;
+        float sloc[(F32_TMAX + 63) / 64];
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kk = 0; kk < (F32_TMAX + 63) / 64; ++kk) {
+            const int key = kk * 64 + lane;
+            float s = -3.0e38f;
+            if (kk * 64 < a.T) {
+                float dot = 0.f;
+                const int kr = key < a.T ? key : a.T - 1;
+                for (int d = 0; d < 64; ++d) dot = fmaf(__shfl(qd, d), sK[kr * 65 + d], dot);
+                if (key <= klimit) s = dot * scale;
+            }
+            sloc[kk] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = wave_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < (F32_TMAX + 63) / 64; ++kk) {
+            const int key = kk * 64 + lane;
+            if (kk * 64 < a.T) {
+                const float p = key <= klimit ? expf(sloc[kk] - mx) : 0.f;
+                if (key < TPAD) myP[key] = p;
+                sum += p;
+            }
+        }
+        sum = wave_sum(sum);
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        float acc = 0.f;
+        for (int key = 0; key <= klimit; ++key) acc = fmaf(myP[key], sV[key * 65 + lane], acc);
+        ((float*)a.out)[((int64_t)b * a.T + q) * a.ld_out + h * 64 + lane] = acc / sum;
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+template <typename T>
+int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
+    const unsigned grid = (unsigned)(B * a.heads);
+    if (a.T <= 32) hipLaunchKernelGGL((attn_rows_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.T <= 96) hipLaunchKernelGGL((attn_rows_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a);
+    else if (a.T <= 224) hipLaunchKernelGGL((attn_rows_kernel<T, 7>), dim3(grid), dim3(256), 0, s, a);
+    else {
+        leclip_set_error("attention: T=%d > 224 needs the streaming kernel (not built in this round)", a.T);
+        return LECLIP_E_UNSUPPORTED;
+    }
+    return leclip_check_launch("attn_rows_kernel");
+}
+
+}  // namespace
+
+extern "C" int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
+                                    int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale,
+                                    leclip_dtype dtype, void* stream) {
+    if (!qkv || !out || B <= 0 || T <= 0 || heads <= 0 || ld_qkv < 3 * heads * 64 || ld_out < heads * 64) {
+        leclip_set_error("attention: null pointer or inconsistent sizes");
+        return LECLIP_E_INVALID;
+    }
+    if (head_dim != 64) { leclip_set_error("attention: head_dim must be 64 (got %d)", head_dim); return LECLIP_E_UNSUPPORTED; }
+    if (!dtype_ok(dtype) || (mask != LECLIP_MASK_NONE && mask != LECLIP_MASK_CAUSAL)) {
+        leclip_set_error("attention: bad enum"); return LECLIP_E_INVALID;
+    }
+    if (B * heads > 0x7fffffff) { leclip_set_error("attention: grid too large"); return LECLIP_E_UNSUPPORTED; }
+    AttnArgs a;
+    a.qkv = qkv; a.out = out; a.T = T; a.heads = heads; a.ld_qkv = ld_qkv; a.ld_out = ld_out;
+    a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LECLIP_F32) {
+        if (T > F32_TMAX) { leclip_set_error("attention(f32): T=%d > %d", T, F32_TMAX); return LECLIP_E_UNSUPPORTED; }
+        if ((ld_qkv % 1) || ((uintptr_t)qkv & 3)) { leclip_set_error("attention(f32): misaligned"); return LECLIP_E_INVALID; }
+        const int TPAD = (T + 63) & ~63;
+        const size_t lds = ((size_t)T * 65 * 2 + 4 * TPAD) * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, a);
+        return leclip_check_launch("attn_f32_kernel");
+    }
+    if ((ld_qkv % 8) || (ld_out % 4) || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) {
+        leclip_set_error("attention: qkv must be 16-byte aligned (ld %% 8 == 0), out 8-byte aligned (ld %% 4 == 0)");
+        return LECLIP_E_INVALID;
+    }
+    return dtype == LECLIP_BF16 ? launch_rows<bf16_t>(a, B, s) : launch_rows<f16_t>(a, B, s);
+}

@@ -1,0 +1,100 @@
+// Exact-fp32 validation GEMM: Y = act(A . W^T + bias) + residual with v_mfma_f32_32x32x2_f32
+// (f32 in / f32 accumulate, bit-for-bit a k-ordered fmaf chain - no reduced-precision path exists on gfx950).
+// This is the "fp32 parity mode" of the scoring path (<= 1e-3 against the CPU reference); it is not the
+// throughput kernel.  64x64 tile per 256-thread workgroup, BK = 32, operands transposed into k-major LDS so
+// every ds_read_b32 is conflict-free; next tile prefetched to registers while the current one is multiplied.
+#include "leclip_common.h"
+
+namespace {
+
+constexpr int FM = 64, FN = 64, FK = 32, LD = 65;
+
+struct GemmF32Args {
+    const float* A;
+    const float* W;
+    int64_t M;
+    int N, K;
+    int64_t lda, ldw;
+    EpiParams epi;
+    int tiles_n;
+};
+
+__global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
+    __shared__ float As[FK * LD];
+    __shared__ float Bs[FK * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * FM;
+    const int n0 = tn * FN;
+
+    // loader mapping: thread -> (row = tid>>2, 8 consecutive k at (tid&3)*8)
+    const int lrow = tid >> 2, lk = (tid & 3) * 8;
+    int64_t arow = m0 + lrow;
+    arow = arow < g.M ? arow : g.M - 1;
+    const float* ap = g.A + arow * g.lda + lk;
+    const float* wp = g.W + (int64_t)(n0 + lrow) * g.ldw + lk;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    f32x4 ra0 = *(const f32x4*)(ap), ra1 = *(const f32x4*)(ap + 4);
+    f32x4 rb0 = *(const f32x4*)(wp), rb1 = *(const f32x4*)(wp + 4);
+    const int nk = g.K / FK;
+    for (int t = 0; t < nk; ++t) {
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            As[(lk + i) * LD + lrow] = ra0[i];
+            As[(lk + 4 + i) * LD + lrow] = ra1[i];
+            Bs[(lk + i) * LD + lrow] = rb0[i];
+            Bs[(lk + 4 + i) * LD + lrow] = rb1[i];
+        }
+        __syncthreads();
+        if (t + 1 < nk) {
+            ra0 = *(const f32x4*)(ap + (t + 1) * FK);
+            ra1 = *(const f32x4*)(ap + (t + 1) * FK + 4);
+            rb0 = *(const f32x4*)(wp + (t + 1) * FK);
+            rb1 = *(const f32x4*)(wp + (t + 1) * FK + 4);
+        }
+        // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]
+        const float* a = As + (lane >> 5) * LD + wr * 32 + (lane & 31);
+        const float* b = Bs + (lane >> 5) * LD + wc * 32 + (lane & 31);
+#pragma unroll
+        for (int k = 0; k < FK; k += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k * LD], b[k * LD], acc, 0, 0, 0);
+    }
+
+    const EpiParams& e = g.epi;
+    const int n = n0 + wc * 32 + (lane & 31);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < g.M) {
+            const float v = epi_apply<true>(e, m, n, acc[r]);
+            store_elem(e.out, e.out_dt, epi_out_row(e, m) * e.ldy + n, v);
+        }
+    }
+}
+
+}  // namespace
+
+int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                           const EpiParams& epi, hipStream_t s) {
+    if (N % FN != 0 || K % FK != 0) {
+        leclip_set_error("gemm(f32): N=%d must be a multiple of %d and K=%d a multiple of %d", N, FN, K, FK);
+        return LECLIP_E_UNSUPPORTED;
+    }
+    if ((lda % 4) || (ldw % 4) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
+        leclip_set_error("gemm(f32): A/W must be 16-byte aligned with leading dimensions that are multiples of 4");
+        return LECLIP_E_INVALID;
+    }
+    GemmF32Args a;
+    a.A = (const float*)A; a.W = (const float*)W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;
+    a.tiles_n = N / FN;
+    const int64_t tiles = ((M + FM - 1) / FM) * a.tiles_n;
+    if (tiles > 0x7fffffff) { leclip_set_error("gemm(f32): too many tiles"); return LECLIP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(gemm_f32_64x64x32, dim3((unsigned)tiles), dim3(256), 0, s, a);
+    return leclip_check_launch("gemm_f32_64x64x32");
+}

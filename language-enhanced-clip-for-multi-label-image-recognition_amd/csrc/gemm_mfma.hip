@@ -1,0 +1,193 @@
+// Y = act(A . W^T + bias) + residual on the gfx950 matrix cores (bf16 / fp16 in, fp32 accumulate).
+//
+// Kernel "gemm_tn_128x128x64": one 256-thread workgroup (4 waves, 2x2) per 128x128 output tile, each wave a
+// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16 accumulators.  A [M,K] and W [N,K] are both K-contiguous, so both
+// operand tiles are [128 rows][64 k] = 128-byte rows.  Tiles are staged HBM -> LDS with 16-byte LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip), double buffered, one barrier per K-step.  The LDS image is
+// lane-linear per wave-instruction (8 rows x 128 B), so the bank-conflict swizzle is applied on the per-lane
+// SOURCE address and again on the ds_read_b128 address: 16-byte chunk q of row r lives at chunk q ^ ((r>>1)&7)
+// (two 128-B rows share one 256-B bank row; the XOR makes each ds_read_b128 16-lane group hit 16 distinct slots).
+// Workgroup ids are remapped so that each XCD (blocks b, b+8, ...) walks a contiguous run of tiles, N fastest:
+// the A row-panel of a tile row is re-read from that XCD's L2, not from HBM.
+#include "leclip_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
+constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered: 64 KiB -> 2 workgroups per CU
+
+struct GemmArgs {
+    const void* A;
+    const void* W;
+    int64_t M;
+    int N, K;
+    int64_t lda, ldw;
+    EpiParams epi;
+    int tiles_n, tiles_total;
+};
+
+// bijective XCD-aware remap (guide T1): blocks with equal id % 8 share an XCD; give each a contiguous chunk.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+template <typename T>
+__device__ __forceinline__ void stage_tile(const T* __restrict__ g, int64_t ld, int64_t row0, int64_t row_max, int k0,
+                                           char* lds_tile, int wave, int lane) {
+    // 16 wave-instructions of 1 KiB (8 rows x 128 B) per tile; wave w issues row-blocks w, w+4, w+8, w+12.
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rb = i * 4 + wave;
+        const int r = rb * 8 + (lane >> 3);
+        const int q = (lane & 7) ^ ((r >> 1) & 7);
+        int64_t gr = row0 + r;
+        gr = gr < row_max ? gr : row_max - 1;   // clamp: out-of-range rows are computed and discarded
+        const T* src = g + gr * ld + k0 + q * 8;
+        __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(lds_tile + rb * 1024), 16, 0, 0);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
+    typedef typename VecOf<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+
+    const int tile = xcd_remap(blockIdx.x, g.tiles_total);
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * BM;
+    const int n0 = tn * BN;
+    const T* A = (const T*)g.A;
+    const T* W = (const T*)g.W;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = g.K / BK;
+    stage_tile<T>(A, g.lda, m0, g.M, 0, smem, wave, lane);
+    stage_tile<T>(W, g.ldw, n0, g.N, 0, smem + TILE_BYTES, wave, lane);
+    __syncthreads();   // with LDS-DMA outstanding this is s_waitcnt vmcnt(0) + s_barrier
+
+    // per-lane fragment addressing: row r = lane&31 of a 32-row MFMA tile, k-chunk 2*kk + (lane>>5)
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int t = 0; t < nk; ++t) {
+        char* cur = smem + (t & 1) * STAGE_BYTES;
+        if (t + 1 < nk) {
+            char* nxt = smem + ((t + 1) & 1) * STAGE_BYTES;
+            stage_tile<T>(A, g.lda, m0, g.M, (t + 1) * BK, nxt, wave, lane);
+            stage_tile<T>(W, g.ldw, n0, g.N, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
+        }
+        const char* sa = cur;
+        const char* sb = cur + TILE_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            v8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int r = wr * 64 + i * 32 + fr;
+                af[i] = *(const v8*)(sa + r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int r = wc * 64 + j * 32 + fr;
+                bfr[j] = *(const v8*)(sb + r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(af[i], bfr[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: accumulator (i,j) register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    const EpiParams& e = g.epi;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+            if (m < g.M) {
+                const int64_t orow = epi_out_row(e, m);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int n = n0 + wc * 64 + j * 32 + fr;
+                    const float v = epi_apply<false>(e, m, n, acc[i][j][r]);
+                    store_elem(e.out, e.out_dt, orow * e.ldy + n, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch_mfma(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_128x128x64<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_128x128x64<T>, dim3(a.tiles_total), dim3(256), LDS_BYTES, s, a);
+    return leclip_check_launch("gemm_tn_128x128x64");
+}
+
+}  // namespace
+
+int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                           const EpiParams& epi, hipStream_t s);
+
+int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                         const EpiParams& epi, int ab_dtype, hipStream_t s) {
+    if (ab_dtype == LECLIP_F32) return leclip_gemm_f32_launch(A, W, M, N, K, lda, ldw, epi, s);
+    if (N % BN != 0 || K % BK != 0) {
+        leclip_set_error("gemm: N=%d must be a multiple of %d and K=%d a multiple of %d for 16-bit operands", N, BN, K, BK);
+        return LECLIP_E_UNSUPPORTED;
+    }
+    if ((lda % 8) || (ldw % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
+        leclip_set_error("gemm: A/W must be 16-byte aligned with leading dimensions that are multiples of 8 elements");
+        return LECLIP_E_INVALID;
+    }
+    GemmArgs a;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;
+    const int64_t tiles_m = (M + BM - 1) / BM;
+    a.tiles_n = N / BN;
+    if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
+    a.tiles_total = (int)(tiles_m * a.tiles_n);
+    return ab_dtype == LECLIP_BF16 ? launch_mfma<bf16_t>(a, s) : launch_mfma<f16_t>(a, s);
+}
+
+extern "C" const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_dtype ab_dtype) {
+    (void)M;
+    if (ab_dtype == LECLIP_F32) return (N % 64 == 0 && K % 32 == 0) ? "gemm_f32_64x64x32" : "unsupported";
+    return (N % BN == 0 && K % BK == 0) ? "gemm_tn_128x128x64" : "unsupported";
+}
+
+extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias, const void* residual,
+                                            void* Y, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr,
+                                            int64_t ldy, leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
+                                            leclip_dtype y_dtype, void* stream) {
+    if (!A || !W || !Y || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldy < N || (residual && ldr < N)) {
+        leclip_set_error("gemm: null pointer or inconsistent sizes (M=%lld N=%d K=%d)", (long long)M, N, K);
+        return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(ab_dtype) || !dtype_ok(y_dtype) || (residual && !dtype_ok(res_dtype)) ||
+        (act != LECLIP_ACT_NONE && act != LECLIP_ACT_QUICKGELU)) {
+        leclip_set_error("gemm: bad dtype / activation enum");
+        return LECLIP_E_INVALID;
+    }
+    EpiParams e;
+    e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
+    e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
+    return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
+}

@@ -1,0 +1,330 @@
+// HBM-bound row-wise kernels of the scoring path: LayerNorm, gather+LayerNorm+projection, L2-normalise + cosine
+// logits, token embedding / prompt assembly, patch extraction.  One wave64 per row where a row reduction is needed
+// (statistics by __shfl_xor butterflies, fp32), 8- or 16-byte vector accesses, no LDS except for the projection.
+#include "leclip_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ LayerNorm
+// One wave per row, 4 rows per workgroup; each lane owns NV vectors of 4 consecutive elements (dim = 256 * NV').
+template <typename TI>
+__device__ __forceinline__ f32x4 load4(const TI* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *(const bf16x4*)p;
+    f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)v[i]; return r;
+}
+template <> __device__ __forceinline__ f32x4 load4<f16_t>(const f16_t* p) {
+    const f16x4 v = *(const f16x4*)p;
+    f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)v[i]; return r;
+}
+template <typename TO>
+__device__ __forceinline__ void store4(TO* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 r; for (int i = 0; i < 4; ++i) r[i] = (bf16_t)v[i]; *(bf16x4*)p = r;
+}
+template <> __device__ __forceinline__ void store4<f16_t>(f16_t* p, f32x4 v) {
+    f16x4 r; for (int i = 0; i < 4; ++i) r[i] = (f16_t)v[i]; *(f16x4*)p = r;
+}
+
+constexpr int LN_MAXV = 16;  // dim <= 4096
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, TO* __restrict__ y,
+                                                        int64_t rows, int dim, int64_t ldx, int64_t ldy, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + row * ldx;
+    const int nv = dim >> 8;            // full 256-element sweeps
+    const int tail = dim & 255;         // remaining elements (multiple of 64): lanes < tail/4 take one more vector
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+            v[i] = load4<TI>(xr + i * 256 + lane * 4);
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    TO* yr = y + row * ldy;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+            const int c = i * 256 + lane * 4;
+            const f32x4 g = *(const f32x4*)(gamma + c), b = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+            store4<TO>(yr + c, o);
+        }
+    }
+}
+
+template <typename TI>
+int ln_dispatch_out(const void* x, const float* g, const float* b, void* y, int64_t rows, int dim, int64_t ldx,
+                    int64_t ldy, float eps, int ydt, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    if (ydt == LECLIP_F32) hipLaunchKernelGGL((layernorm_kernel<TI, float>), grid, block, 0, s, (const TI*)x, g, b, (float*)y, rows, dim, ldx, ldy, eps);
+    else if (ydt == LECLIP_F16) hipLaunchKernelGGL((layernorm_kernel<TI, f16_t>), grid, block, 0, s, (const TI*)x, g, b, (f16_t*)y, rows, dim, ldx, ldy, eps);
+    else hipLaunchKernelGGL((layernorm_kernel<TI, bf16_t>), grid, block, 0, s, (const TI*)x, g, b, (bf16_t*)y, rows, dim, ldx, ldy, eps);
+    return leclip_check_launch("layernorm_kernel");
+}
+
+// ------------------------------------------------------------------------- gather + LayerNorm + projection
+// One workgroup per output row: the gathered row is normalised into LDS (fp32), then thread e accumulates
+// out[e] = sum_k xn[k] * proj[k][e] reading proj rows coalesced across threads.
+__global__ __launch_bounds__(256) void gather_ln_proj_kernel(const void* __restrict__ x, const int64_t* __restrict__ rows,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             const void* __restrict__ proj, float* __restrict__ out,
+                                                             int dim, int E, int64_t ldx, float eps, int xdt, int pdt) {
+    extern __shared__ float xn[];   // [dim] + 8 scratch
+    float* red = xn + dim;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r = rows ? rows[blockIdx.x] : (int64_t)blockIdx.x;
+    float s = 0.f;
+    for (int k = tid; k < dim; k += 256) { const float v = load_elem(x, xdt, r * ldx + k); xn[k] = v; s += v; }
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    const float mean = (red[0] + red[1] + red[2] + red[3]) / (float)dim;
+    float q = 0.f;
+    for (int k = tid; k < dim; k += 256) { const float d = xn[k] - mean; q = fmaf(d, d, q); }
+    q = wave_sum(q);
+    if (lane == 0) red[4 + wave] = q;
+    __syncthreads();
+    const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)dim + eps);
+    for (int k = tid; k < dim; k += 256) xn[k] = (xn[k] - mean) * rstd * gamma[k] + beta[k];
+    __syncthreads();
+    for (int e = tid; e < E; e += 256) {
+        float acc = 0.f;
+        if (pdt == LECLIP_F32) { const float* p = (const float*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], p[(int64_t)k * E], acc); }
+        else if (pdt == LECLIP_F16) { const f16_t* p = (const f16_t*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], (float)p[(int64_t)k * E], acc); }
+        else { const bf16_t* p = (const bf16_t*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], (float)p[(int64_t)k * E], acc); }
+        out[(int64_t)blockIdx.x * E + e] = acc;
+    }
+}
+
+// --------------------------------------------------------------------- L2 normalise + scaled cosine logits
+// Workgroup = 4 waves = 4 image rows; the text matrix [C,D] streams from L2.  Per (image, class) one wave dot
+// product would waste lanes, so each wave keeps its image row in registers (D/64 per lane) and loops classes.
+constexpr int LG_MAXV = 32;  // D <= 2048
+__global__ __launch_bounds__(256) void l2norm_logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                            float* __restrict__ logits, int64_t B, int C, int D, float scale) {
+    extern __shared__ float tinv[];  // [C] inverse text norms
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int c = wave; c < C; c += 4) {
+        float s = 0.f;
+        for (int k = lane; k < D; k += 64) { const float v = txt[(int64_t)c * D + k]; s = fmaf(v, v, s); }
+        s = wave_sum(s);
+        if (lane == 0) tinv[c] = 1.0f / sqrtf(s);
+    }
+    __syncthreads();
+    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
+    if (b >= B) return;
+    float x[LG_MAXV];
+    float s = 0.f;
+    const int nv = D >> 6;
+#pragma unroll
+    for (int i = 0; i < LG_MAXV; ++i)
+        if (i < nv) { x[i] = img[b * D + i * 64 + lane]; s = fmaf(x[i], x[i], s); }
+    const float si = scale / sqrtf(wave_sum(s));
+#pragma unroll
+    for (int i = 0; i < LG_MAXV; ++i)
+        if (i < nv) x[i] *= si;                      // (scale * img/||img||) first, as `a * b @ c` parses
+    for (int c = 0; c < C; ++c) {
+        float d = 0.f;
+        const float ti = tinv[c];
+#pragma unroll
+        for (int i = 0; i < LG_MAXV; ++i)
+            if (i < nv) d = fmaf(x[i], txt[(int64_t)c * D + i * 64 + lane] * ti, d);
+        d = wave_sum(d);
+        if (lane == 0) logits[b * C + c] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------ embeddings / prompt assembly
+__global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
+                                    const float* __restrict__ pos, void* __restrict__ x, int64_t n_rows, int T, int dim,
+                                    int64_t vocab, int xdt) {
+    const int64_t row = blockIdx.x;
+    if (row >= n_rows) return;
+    int64_t tok = tokens[row];
+    tok = tok < 0 ? 0 : (tok >= vocab ? vocab - 1 : tok);
+    const int t = (int)(row % T);
+    for (int k = threadIdx.x; k < dim; k += blockDim.x)
+        store_elem(x, xdt, row * dim + k, table[tok * dim + k] + pos[(int64_t)t * dim + k]);
+}
+
+__global__ void prompt_assemble_kernel(const float* __restrict__ prefix, const float* __restrict__ ctx,
+                                       const float* __restrict__ suffix, const float* __restrict__ pos,
+                                       void* __restrict__ x, int n_ctx, int T, int dim, int ctx_per_class, int xdt) {
+    const int64_t row = blockIdx.x;        // c * T + t
+    const int64_t c = row / T;
+    const int t = (int)(row - c * T);
+    const float* src;
+    if (t == 0) src = prefix + c * dim;
+    else if (t <= n_ctx) src = ctx + ((ctx_per_class ? c * n_ctx : 0) + (t - 1)) * (int64_t)dim;
+    else src = suffix + (c * (T - 1 - n_ctx) + (t - 1 - n_ctx)) * (int64_t)dim;
+    for (int k = threadIdx.x; k < dim; k += blockDim.x)
+        store_elem(x, xdt, row * dim + k, src[k] + pos[(int64_t)t * dim + k]);
+}
+
+__global__ void eot_index_kernel(const int64_t* __restrict__ tokens, int64_t* __restrict__ eot,
+                                 int64_t* __restrict__ flat, int64_t n, int T) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    int64_t best = tokens[r * T];
+    int bi = 0;
+    for (int t = 1; t < T; ++t) { const int64_t v = tokens[r * T + t]; if (v > best) { best = v; bi = t; } }
+    if (eot) eot[r] = bi;
+    if (flat) flat[r] = r * T + bi;
+}
+
+// ------------------------------------------------------------------------------------------ patch extraction
+// patches[(b,gy,gx)][(c,py,px)] = image[b][c][gy*P+py][gx*P+px]; one thread per (row, c, py) run of P pixels.
+__global__ void im2col_kernel(const void* __restrict__ image, void* __restrict__ patches, int64_t B, int R, int P, int Kp,
+                              int idt, int odt) {
+    const int G = R / P;
+    const int64_t total = B * G * G * 3 * P;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int py = (int)(i % P);
+    int64_t r = i / P;
+    const int c = (int)(r % 3);
+    r /= 3;                                  // patch row index (b, gy, gx)
+    const int gx = (int)(r % G);
+    const int gy = (int)((r / G) % G);
+    const int64_t b = r / ((int64_t)G * G);
+    const int64_t src = ((b * 3 + c) * R + (gy * P + py)) * (int64_t)R + gx * P;
+    const int64_t dst = r * Kp + (c * P + py) * P;
+    for (int px = 0; px < P; ++px) store_elem(patches, odt, dst + px, load_elem(image, idt, src + px));
+    if (c == 2 && py == P - 1)
+        for (int k = 3 * P * P; k < Kp; ++k) store_elem(patches, odt, r * Kp + k, 0.f);
+}
+
+__global__ void class_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, void* __restrict__ X,
+                                  int T, int width, int xdt) {
+    const int64_t b = blockIdx.x;
+    for (int k = threadIdx.x; k < width; k += blockDim.x)
+        store_elem(X, xdt, b * T * (int64_t)width + k, cls[k] + pos[k]);
+}
+
+}  // namespace
+
+int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                         const EpiParams& epi, int ab_dtype, hipStream_t s);
+
+extern "C" int leclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int dim,
+                                    int64_t ldx, int64_t ldy, float eps, leclip_dtype x_dtype, leclip_dtype y_dtype,
+                                    void* stream) {
+    if (!x || !gamma || !beta || !y || rows <= 0 || dim <= 0 || ldx < dim || ldy < dim) {
+        leclip_set_error("layernorm: null pointer or inconsistent sizes"); return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(x_dtype) || !dtype_ok(y_dtype)) { leclip_set_error("layernorm: bad dtype"); return LECLIP_E_INVALID; }
+    if (dim % 64 != 0 || dim > 256 * LN_MAXV) {
+        leclip_set_error("layernorm: dim=%d must be a multiple of 64 and <= %d", dim, 256 * LN_MAXV); return LECLIP_E_UNSUPPORTED;
+    }
+    if ((ldx % 4) || (ldy % 4) || ((uintptr_t)x & 7) || ((uintptr_t)y & 7) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) {
+        leclip_set_error("layernorm: rows must be 8-byte aligned (ld %% 4 == 0), gamma/beta 16-byte aligned"); return LECLIP_E_INVALID;
+    }
+    if (x_dtype == LECLIP_F32 && (((uintptr_t)x & 15))) { leclip_set_error("layernorm: fp32 input must be 16-byte aligned"); return LECLIP_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == LECLIP_F32) return ln_dispatch_out<float>(x, gamma, beta, y, rows, dim, ldx, ldy, eps, y_dtype, s);
+    if (x_dtype == LECLIP_F16) return ln_dispatch_out<f16_t>(x, gamma, beta, y, rows, dim, ldx, ldy, eps, y_dtype, s);
+    return ln_dispatch_out<bf16_t>(x, gamma, beta, y, rows, dim, ldx, ldy, eps, y_dtype, s);
+}
+
+extern "C" int leclip_gather_ln_proj_fwd(const void* x, const int64_t* row_index, const float* gamma, const float* beta,
+                                         const void* proj, float* out, int64_t n, int dim, int E, int64_t ldx, float eps,
+                                         leclip_dtype x_dtype, leclip_dtype proj_dtype, void* stream) {
+    if (!x || !gamma || !beta || !proj || !out || n <= 0 || dim <= 0 || E <= 0 || ldx < dim) {
+        leclip_set_error("gather_ln_proj: null pointer or inconsistent sizes"); return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(x_dtype) || !dtype_ok(proj_dtype)) { leclip_set_error("gather_ln_proj: bad dtype"); return LECLIP_E_INVALID; }
+    if (dim > 8192) { leclip_set_error("gather_ln_proj: dim=%d > 8192", dim); return LECLIP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(gather_ln_proj_kernel, dim3((unsigned)n), dim3(256), (dim + 8) * sizeof(float), (hipStream_t)stream,
+                       x, row_index, gamma, beta, proj, out, dim, E, ldx, eps, (int)x_dtype, (int)proj_dtype);
+    return leclip_check_launch("gather_ln_proj_kernel");
+}
+
+extern "C" int leclip_l2norm_logits_fwd(const float* img, const float* txt, float* logits, int64_t B, int C, int D,
+                                        float scale, void* stream) {
+    if (!img || !txt || !logits || B <= 0 || C <= 0 || D <= 0) { leclip_set_error("logits: null pointer or bad size"); return LECLIP_E_INVALID; }
+    if (D % 64 != 0 || D > 64 * LG_MAXV || C > 8192) {
+        leclip_set_error("logits: D=%d must be a multiple of 64 and <= %d; C=%d <= 8192", D, 64 * LG_MAXV, C); return LECLIP_E_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(l2norm_logits_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), C * sizeof(float), (hipStream_t)stream,
+                       img, txt, logits, B, C, D, scale);
+    return leclip_check_launch("l2norm_logits_kernel");
+}
+
+extern "C" int leclip_embed_tokens_fwd(const int64_t* tokens, const float* table, const float* pos, void* x, int64_t n, int T,
+                                       int dim, int64_t vocab, leclip_dtype x_dtype, void* stream) {
+    if (!tokens || !table || !pos || !x || n <= 0 || T <= 0 || dim <= 0 || vocab <= 0 || !dtype_ok(x_dtype)) {
+        leclip_set_error("embed_tokens: null pointer or bad size"); return LECLIP_E_INVALID;
+    }
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)(n * T)), dim3(128), 0, (hipStream_t)stream, tokens, table, pos, x,
+                       n * T, T, dim, vocab, (int)x_dtype);
+    return leclip_check_launch("embed_tokens_kernel");
+}
+
+extern "C" int leclip_prompt_assemble_fwd(const float* prefix, const float* ctx, const float* suffix, const float* pos, void* x,
+                                          int64_t n_cls, int n_ctx, int T, int dim, int ctx_per_class, leclip_dtype x_dtype,
+                                          void* stream) {
+    if (!prefix || !ctx || !suffix || !pos || !x || n_cls <= 0 || n_ctx < 0 || T <= 1 + n_ctx || dim <= 0 || !dtype_ok(x_dtype)) {
+        leclip_set_error("prompt_assemble: null pointer or bad size"); return LECLIP_E_INVALID;
+    }
+    hipLaunchKernelGGL(prompt_assemble_kernel, dim3((unsigned)(n_cls * T)), dim3(128), 0, (hipStream_t)stream, prefix, ctx, suffix,
+                       pos, x, n_ctx, T, dim, ctx_per_class, (int)x_dtype);
+    return leclip_check_launch("prompt_assemble_kernel");
+}
+
+extern "C" int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream) {
+    if (!tokens || (!eot && !flat_row) || n <= 0 || T <= 0) { leclip_set_error("eot_index: null pointer or bad size"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(eot_index_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, (hipStream_t)stream, tokens, eot, flat_row, n, T);
+    return leclip_check_launch("eot_index_kernel");
+}
+
+static inline int patch_kp(int P, int w_dtype) { const int k = 3 * P * P, a = w_dtype == LECLIP_F32 ? 32 : 64; return (k + a - 1) / a * a; }
+
+extern "C" int64_t leclip_patch_embed_workspace_bytes(int64_t B, int R, int P, leclip_dtype w_dtype) {
+    if (B <= 0 || R <= 0 || P <= 0 || R % P) return LECLIP_E_INVALID;
+    const int64_t G = R / P;
+    return B * G * G * patch_kp(P, w_dtype) * dtype_size(w_dtype);
+}
+
+extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, void* X,
+                                      int64_t B, int R, int P, int width, leclip_dtype img_dtype, leclip_dtype w_dtype,
+                                      leclip_dtype x_dtype, void* workspace, void* stream) {
+    if (!image || !Wp || !class_emb || !pos || !X || !workspace || B <= 0 || R <= 0 || P <= 0 || R % P || width <= 0) {
+        leclip_set_error("patch_embed: null pointer or inconsistent sizes"); return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(img_dtype) || !dtype_ok(w_dtype) || !dtype_ok(x_dtype)) { leclip_set_error("patch_embed: bad dtype"); return LECLIP_E_INVALID; }
+    hipStream_t s = (hipStream_t)stream;
+    const int G = R / P, T = G * G + 1, Kp = patch_kp(P, w_dtype);
+    const int64_t total = B * G * G * 3 * P;
+    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp,
+                       (int)img_dtype, (int)w_dtype);
+    int rc = leclip_check_launch("im2col_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(class_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, class_emb, pos, X, T, width, (int)x_dtype);
+    rc = leclip_check_launch("class_rows_kernel");
+    if (rc) return rc;
+    EpiParams e;
+    e.bias = nullptr; e.res = pos; e.out = X; e.ldr = width; e.ldy = width;
+    e.res_dt = LECLIP_F32; e.out_dt = x_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = G * G;
+    return leclip_gemm_dispatch(workspace, Wp, B * G * G, width, Kp, Kp, Kp, e, w_dtype, s);
+}

@@ -1,0 +1,197 @@
+// Standalone (no Python) correctness + timing harness for libleclip_hip.so, used during kernel development:
+//   kernel_check            -> correctness of GEMM / attention against a CPU double-precision reference
+//   kernel_check bench      -> timings of the ViT-B/16 B=256 shapes
+// Build: hipcc -O2 --offload-arch=gfx950 kernel_check.cpp -L../lib -lleclip_hip -o ../../lib/leclip_kernel_check
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <functional>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../../../include/leclip_hip.h"
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+static uint16_t f2h(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
+static float h2f(uint16_t u) { _Float16 h; memcpy(&h, &u, 2); return (float)h; }
+
+struct Buf {
+    void* d = nullptr; size_t bytes = 0;
+    explicit Buf(size_t b) : bytes(b) { HIPCHK(hipMalloc(&d, b)); }
+    ~Buf() { if (d) (void)hipFree(d); }
+    void up(const void* h) { HIPCHK(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); }
+    void down(void* h) { HIPCHK(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); }
+};
+
+static std::mt19937 rng(12345);
+static std::vector<float> randn(size_t n, float s = 1.f) { std::normal_distribution<float> d(0.f, s); std::vector<float> v(n); for (auto& x : v) x = d(rng); return v; }
+
+// quantise to dtype and keep the rounded value in fp32 for the reference
+static std::vector<uint8_t> pack(std::vector<float>& v, int dt) {
+    std::vector<uint8_t> out(v.size() * (dt == LECLIP_F32 ? 4 : 2));
+    for (size_t i = 0; i < v.size(); ++i) {
+        if (dt == LECLIP_F32) memcpy(&out[4 * i], &v[i], 4);
+        else if (dt == LECLIP_BF16) { uint16_t h = f2bf(v[i]); v[i] = bf2f(h); memcpy(&out[2 * i], &h, 2); }
+        else { uint16_t h = f2h(v[i]); v[i] = h2f(h); memcpy(&out[2 * i], &h, 2); }
+    }
+    return out;
+}
+static float unpack1(const uint8_t* p, int dt, size_t i) {
+    if (dt == LECLIP_F32) { float f; memcpy(&f, p + 4 * i, 4); return f; }
+    uint16_t h; memcpy(&h, p + 2 * i, 2);
+    return dt == LECLIP_BF16 ? bf2f(h) : h2f(h);
+}
+static const char* dtn(int dt) { return dt == LECLIP_F32 ? "f32" : dt == LECLIP_F16 ? "f16" : "bf16"; }
+
+static int g_fail = 0;
+
+static void check_gemm(int64_t M, int N, int K, int ab, int resdt, int outdt, int act, bool bias, bool res) {
+    auto A = randn(M * K), W = randn((size_t)N * K, 1.f / std::sqrt((float)K)), B = randn(N), R = randn(M * N);
+    auto Ap = pack(A, ab), Wp = pack(W, ab), Rp = pack(R, resdt);
+    Buf dA(Ap.size()), dW(Wp.size()), dB(N * 4), dR(Rp.size()), dY((size_t)M * N * (outdt == LECLIP_F32 ? 4 : 2));
+    dA.up(Ap.data()); dW.up(Wp.data()); dB.up(B.data()); dR.up(Rp.data());
+    HIPCHK(hipMemset(dY.d, 0xFF, dY.bytes));
+    int rc = leclip_gemm_bias_act_res_fwd(dA.d, dW.d, bias ? (float*)dB.d : nullptr, res ? dR.d : nullptr, dY.d, M, N, K, K, K, N, N,
+                                          (leclip_act)act, (leclip_dtype)ab, (leclip_dtype)resdt, (leclip_dtype)outdt, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    if (rc) { printf("FAIL gemm rc=%d %s\n", rc, leclip_last_error()); g_fail++; return; }
+    std::vector<uint8_t> Y(dY.bytes); dY.down(Y.data());
+    double maxerr = 0, maxref = 0;
+    for (int64_t m = 0; m < M; ++m) for (int n = 0; n < N; ++n) {
+        double acc = 0;
+        for (int k = 0; k < K; ++k) acc += (double)A[m * K + k] * W[(size_t)n * K + k];
+        if (bias) acc += B[n];
+        if (act) acc = acc / (1.0 + std::exp(-1.702 * acc));
+        if (res) acc += R[m * N + n];
+        double got = unpack1(Y.data(), outdt, m * N + n);
+        maxerr = std::max(maxerr, std::fabs(got - acc)); maxref = std::max(maxref, std::fabs(acc));
+    }
+    double tol = outdt == LECLIP_F32 ? (ab == LECLIP_F32 ? 2e-5 : 2e-3) * maxref : (outdt == LECLIP_BF16 ? 8e-3 : 2e-3) * maxref;
+    bool ok = maxerr <= tol && maxerr == maxerr;
+    printf("%s gemm M=%lld N=%d K=%d ab=%s res=%s out=%s act=%d bias=%d: maxerr %.3e (ref max %.2f, tol %.2e)\n", ok ? "ok  " : "FAIL",
+           (long long)M, N, K, dtn(ab), res ? dtn(resdt) : "-", dtn(outdt), act, bias, maxerr, maxref, tol);
+    if (!ok) g_fail++;
+}
+
+static void check_attn(int B, int T, int heads, int dt, int causal) {
+    const int d = heads * 64;
+    auto Q = randn((size_t)B * T * 3 * d);
+    auto Qp = pack(Q, dt);
+    Buf dQ(Qp.size()), dO((size_t)B * T * d * (dt == LECLIP_F32 ? 4 : 2));
+    dQ.up(Qp.data());
+    HIPCHK(hipMemset(dO.d, 0xFF, dO.bytes));
+    int rc = leclip_attention_fwd(dQ.d, dO.d, B, T, heads, 64, 3 * d, d, causal ? LECLIP_MASK_CAUSAL : LECLIP_MASK_NONE, 0.125f, (leclip_dtype)dt, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    if (rc) { printf("FAIL attn rc=%d %s\n", rc, leclip_last_error()); g_fail++; return; }
+    std::vector<uint8_t> O(dO.bytes); dO.down(O.data());
+    double maxerr = 0;
+    std::vector<double> s(T);
+    for (int b = 0; b < B; ++b) for (int h = 0; h < heads; ++h) for (int q = 0; q < T; ++q) {
+        const float* qr = &Q[((size_t)b * T + q) * 3 * d + h * 64];
+        double mx = -1e300;
+        int kl = causal ? q : T - 1;
+        for (int k = 0; k <= kl; ++k) {
+            const float* kr = &Q[((size_t)b * T + k) * 3 * d + d + h * 64];
+            double acc = 0; for (int e = 0; e < 64; ++e) acc += (double)qr[e] * kr[e];
+            s[k] = acc * 0.125; mx = std::max(mx, s[k]);
+        }
+        double sum = 0; for (int k = 0; k <= kl; ++k) { s[k] = std::exp(s[k] - mx); sum += s[k]; }
+        for (int e = 0; e < 64; ++e) {
+            double acc = 0;
+            for (int k = 0; k <= kl; ++k) acc += s[k] * Q[((size_t)b * T + k) * 3 * d + 2 * d + h * 64 + e];
+            acc /= sum;
+            double got = unpack1(O.data(), dt, ((size_t)b * T + q) * d + h * 64 + e);
+            maxerr = std::max(maxerr, std::fabs(got - acc));
+        }
+    }
+    double tol = dt == LECLIP_F32 ? 2e-5 : (dt == LECLIP_BF16 ? 2.5e-2 : 4e-3);
+    bool ok = maxerr <= tol && maxerr == maxerr;
+    printf("%s attn B=%d T=%d heads=%d %s causal=%d: maxerr %.3e (tol %.1e)\n", ok ? "ok  " : "FAIL", B, T, heads, dtn(dt), causal, maxerr, tol);
+    if (!ok) g_fail++;
+}
+
+static void check_gemm_identity() {
+    // A = I (128x128, K=128), asymmetric W: catches transposed / permuted fragment maps exactly
+    const int M = 128, N = 128, K = 128;
+    std::vector<float> A(M * K, 0.f), W((size_t)N * K);
+    for (int i = 0; i < M; ++i) A[i * K + i] = 1.f;
+    for (int n = 0; n < N; ++n) for (int k = 0; k < K; ++k) W[(size_t)n * K + k] = (float)((n * 3 + k * 7) % 64) - 20.f;
+    auto Ap = pack(A, LECLIP_BF16), Wp = pack(W, LECLIP_BF16);
+    Buf dA(Ap.size()), dW(Wp.size()), dY(M * N * 4);
+    dA.up(Ap.data()); dW.up(Wp.data());
+    int rc = leclip_gemm_bias_act_res_fwd(dA.d, dW.d, nullptr, nullptr, dY.d, M, N, K, K, K, N, N, LECLIP_ACT_NONE, LECLIP_BF16, LECLIP_F32, LECLIP_F32, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<float> Y(M * N); dY.down(Y.data());
+    int bad = 0;
+    for (int m = 0; m < M; ++m) for (int n = 0; n < N; ++n) if (Y[m * N + n] != W[(size_t)n * K + m]) bad++;
+    printf("%s gemm identity/asymmetric exact check rc=%d mismatches=%d\n", (bad == 0 && rc == 0) ? "ok  " : "FAIL", rc, bad);
+    if (bad || rc) g_fail++;
+}
+
+static double time_ms(int iters, const std::function<void()>& fn) {
+    hipEvent_t a, b; HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) fn();
+    HIPCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) fn();
+    HIPCHK(hipEventRecord(b, nullptr)); HIPCHK(hipEventSynchronize(b));
+    float ms; HIPCHK(hipEventElapsedTime(&ms, a, b));
+    return ms / iters;
+}
+
+static void bench() {
+    const int64_t M = 256 * 197;
+    struct S { int N, K, act; bool res; const char* name; } shapes[] = {
+        {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
+    for (int dt : {LECLIP_BF16, LECLIP_F16}) for (auto& s : shapes) {
+        auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
+        auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
+        Buf dA(Ap.size()), dW(Wp.size()), dB(s.N * 4), dR(Rp.size()), dY((size_t)M * s.N * 2);
+        dA.up(Ap.data()); dW.up(Wp.data()); dB.up(Bv.data()); dR.up(Rp.data());
+        double ms = time_ms(20, [&] {
+            leclip_gemm_bias_act_res_fwd(dA.d, dW.d, (float*)dB.d, s.res ? dR.d : nullptr, dY.d, M, s.N, s.K, s.K, s.K, s.N, s.N,
+                                         (leclip_act)s.act, (leclip_dtype)dt, (leclip_dtype)dt, (leclip_dtype)dt, nullptr);
+        });
+        printf("bench gemm %-10s %s M=%lld N=%d K=%d: %.3f ms  %.1f TFLOP/s\n", s.name, dtn(dt), (long long)M, s.N, s.K, ms, 2.0 * M * s.N * s.K / ms * 1e-9);
+    }
+    {
+        const int B = 256, T = 197, heads = 12, d = 768;
+        auto Q = randn((size_t)B * T * 3 * d);
+        auto Qp = pack(Q, LECLIP_BF16);
+        Buf dQ(Qp.size()), dO((size_t)B * T * d * 2);
+        dQ.up(Qp.data());
+        double ms = time_ms(20, [&] { leclip_attention_fwd(dQ.d, dO.d, B, T, heads, 64, 3 * d, d, LECLIP_MASK_NONE, 0.125f, LECLIP_BF16, nullptr); });
+        printf("bench attn B=256 T=197 h=12 bf16: %.3f ms  %.1f TFLOP/s (4*T*T*64 per head)\n", ms, 4.0 * T * T * 64 * B * heads / ms * 1e-9);
+        auto X = randn((size_t)M * d), G = randn(d), Bt = randn(d);
+        auto Xp = pack(X, LECLIP_BF16);
+        Buf dX(Xp.size()), dG(d * 4), dBt(d * 4), dYn((size_t)M * d * 2);
+        dX.up(Xp.data()); dG.up(G.data()); dBt.up(Bt.data());
+        ms = time_ms(20, [&] { leclip_layernorm_fwd(dX.d, (float*)dG.d, (float*)dBt.d, dYn.d, M, d, d, d, 1e-5f, LECLIP_BF16, LECLIP_BF16, nullptr); });
+        printf("bench layernorm rows=%lld dim=768 bf16->bf16: %.3f ms  %.1f GB/s\n", (long long)M, ms, 2.0 * M * d * 2 / ms * 1e-6);
+    }
+}
+
+int main(int argc, char** argv) {
+    printf("leclip ABI %d\n", leclip_abi_version());
+    if (argc > 1 && !strcmp(argv[1], "bench")) { bench(); return 0; }
+    check_gemm_identity();
+    for (int dt : {LECLIP_BF16, LECLIP_F16}) {
+        check_gemm(200, 128, 64, dt, LECLIP_F32, LECLIP_F32, 0, false, false);
+        check_gemm(1576, 768, 768, dt, dt, dt, 0, true, true);
+        check_gemm(333, 384, 192, dt, LECLIP_F32, dt, 1, true, false);
+        check_gemm(1576, 256, 3072, dt, LECLIP_F32, LECLIP_F32, 1, true, true);
+    }
+    check_gemm(200, 64, 32, LECLIP_F32, LECLIP_F32, LECLIP_F32, 0, false, false);
+    check_gemm(777, 192, 160, LECLIP_F32, LECLIP_F32, LECLIP_F32, 1, true, true);
+    for (int dt : {LECLIP_BF16, LECLIP_F16, LECLIP_F32}) {
+        check_attn(2, 197, 3, dt, 0);
+        check_attn(3, 77, 2, dt, 1);
+        check_attn(2, 17, 2, dt, 0);
+        check_attn(1, 50, 1, dt, 1);
+    }
+    printf(g_fail ? "FAILED %d checks\n" : "ALL OK\n", g_fail);
+    return g_fail ? 1 : 0;
+}
