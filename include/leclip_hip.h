@@ -100,10 +100,16 @@ int leclip_embed_tokens_fwd(const int64_t* tokens, const float* table, const flo
 
 /* x[c, :, :] = cat(prefix[c] (1 row), ctx (n_ctx rows; generic [n_ctx,dim] if ctx_per_class == 0 else [n_cls,n_ctx,dim]),
  *                  suffix[c] (T-1-n_ctx rows)) + pos      - PromptLearner.forward 'end' layout + TextEncoder's
- * positional add (trainers/Caption_distill_double.py:206-225, 86).  All inputs fp32; x in x_dtype. */
+ * positional add (trainers/Caption_distill_double.py:206-225, 86).  All inputs fp32; pos may be NULL
+ * (plain PromptLearner.forward concat); x in x_dtype. */
 int leclip_prompt_assemble_fwd(const float* prefix, const float* ctx, const float* suffix, const float* pos, void* x,
                                int64_t n_cls, int n_ctx, int T, int dim, int ctx_per_class,
                                leclip_dtype x_dtype, void* stream);
+
+/* x[n, t, :] = in[n, t, :] + pos[t, :] with a cast to x_dtype: TextEncoder.forward's `prompts + positional_embedding`
+ * on an already assembled fp32 prompt tensor (trainers/Caption_distill_double.py:86). */
+int leclip_add_pos_fwd(const float* in, const float* pos, void* x, int64_t n, int T, int dim, leclip_dtype x_dtype,
+                       void* stream);
 
 /* Index of the maximum token id per row (first occurrence), = tokens.argmax(-1) (clip/model.py:390), plus the flat
  * row n*T + argmax used by leclip_gather_ln_proj_fwd. */

@@ -179,7 +179,15 @@ __global__ void prompt_assemble_kernel(const float* __restrict__ prefix, const f
     else if (t <= n_ctx) src = ctx + ((ctx_per_class ? c * n_ctx : 0) + (t - 1)) * (int64_t)dim;
     else src = suffix + (c * (T - 1 - n_ctx) + (t - 1 - n_ctx)) * (int64_t)dim;
     for (int k = threadIdx.x; k < dim; k += blockDim.x)
-        store_elem(x, xdt, row * dim + k, src[k] + pos[(int64_t)t * dim + k]);
+        store_elem(x, xdt, row * dim + k, src[k] + (pos ? pos[(int64_t)t * dim + k] : 0.f));
+}
+
+__global__ void add_pos_kernel(const float* __restrict__ in, const float* __restrict__ pos, void* __restrict__ x, int T, int dim,
+                               int xdt) {
+    const int64_t row = blockIdx.x;
+    const int t = (int)(row % T);
+    for (int k = threadIdx.x; k < dim; k += blockDim.x)
+        store_elem(x, xdt, row * dim + k, in[row * dim + k] + pos[(int64_t)t * dim + k]);
 }
 
 __global__ void eot_index_kernel(const int64_t* __restrict__ tokens, int64_t* __restrict__ eot,
@@ -284,12 +292,21 @@ extern "C" int leclip_embed_tokens_fwd(const int64_t* tokens, const float* table
 extern "C" int leclip_prompt_assemble_fwd(const float* prefix, const float* ctx, const float* suffix, const float* pos, void* x,
                                           int64_t n_cls, int n_ctx, int T, int dim, int ctx_per_class, leclip_dtype x_dtype,
                                           void* stream) {
-    if (!prefix || !ctx || !suffix || !pos || !x || n_cls <= 0 || n_ctx < 0 || T <= 1 + n_ctx || dim <= 0 || !dtype_ok(x_dtype)) {
+    if (!prefix || !ctx || !suffix || !x || n_cls <= 0 || n_ctx < 0 || T <= 1 + n_ctx || dim <= 0 || !dtype_ok(x_dtype)) {
         leclip_set_error("prompt_assemble: null pointer or bad size"); return LECLIP_E_INVALID;
     }
     hipLaunchKernelGGL(prompt_assemble_kernel, dim3((unsigned)(n_cls * T)), dim3(128), 0, (hipStream_t)stream, prefix, ctx, suffix,
                        pos, x, n_ctx, T, dim, ctx_per_class, (int)x_dtype);
     return leclip_check_launch("prompt_assemble_kernel");
+}
+
+extern "C" int leclip_add_pos_fwd(const float* in, const float* pos, void* x, int64_t n, int T, int dim, leclip_dtype x_dtype,
+                                  void* stream) {
+    if (!in || !pos || !x || n <= 0 || T <= 0 || dim <= 0 || !dtype_ok(x_dtype)) {
+        leclip_set_error("add_pos: null pointer or bad size"); return LECLIP_E_INVALID;
+    }
+    hipLaunchKernelGGL(add_pos_kernel, dim3((unsigned)(n * T)), dim3(128), 0, (hipStream_t)stream, in, pos, x, T, dim, (int)x_dtype);
+    return leclip_check_launch("add_pos_kernel");
 }
 
 extern "C" int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream) {

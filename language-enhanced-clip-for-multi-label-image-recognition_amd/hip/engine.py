@@ -1,0 +1,187 @@
+"""Tower engines: weight packing and the kernel sequence of the two CLIP towers.
+
+Data layout in HBM (all row-major, token-major within an image / prompt):
+
+* residual stream  ``x``   [B*T, d]      compute dtype (bf16 / fp16 / fp32), updated in place by the
+                                         out-proj and c_proj GEMM epilogues (bias + residual fused);
+* LayerNorm output ``h``   [B*T, d]      compute dtype, the A operand of the next GEMM;
+* packed QKV       ``qkv`` [B*T, 3d]     compute dtype, columns q|k|v in in_proj order; attention reads the
+                                         128-byte (b, t, head) rows in place - no head-major re-layout;
+* attention output ``ctx`` [B*T, d]      compute dtype; MLP hidden ``u`` [B*T, 4d] (QuickGELU fused in c_fc);
+* weights [N, K] (nn.Linear layout, K contiguous) in the compute dtype; biases, LayerNorm affine,
+  class / positional embeddings, token table in fp32.
+
+One forward of a tower with L blocks is 1 + 7L + 1 kernel launches (patch-embed adds 2) on the
+caller's current HIP stream; nothing synchronises and all workspaces are cached per batch size.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import ops
+from ._capi import ACT_NONE, ACT_QUICKGELU
+
+
+def _f32(t: torch.Tensor, device) -> torch.Tensor:
+    return t.detach().to(device=device, dtype=torch.float32).contiguous()
+
+
+class _Block:
+    __slots__ = ("ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_pr", "b_pr")
+
+
+def pack_blocks(resblocks, dtype: torch.dtype, device):
+    """Pack the parameters of a ``Transformer``'s blocks (clip/model.py:207-228 layout)."""
+    out = []
+    for blk in resblocks:
+        p = _Block()
+        p.ln1_w, p.ln1_b = _f32(blk.ln_1.weight, device), _f32(blk.ln_1.bias, device)
+        p.ln2_w, p.ln2_b = _f32(blk.ln_2.weight, device), _f32(blk.ln_2.bias, device)
+        p.w_qkv = blk.attn.in_proj_weight.detach().to(device=device, dtype=dtype).contiguous()
+        p.b_qkv = _f32(blk.attn.in_proj_bias, device)
+        p.w_o = blk.attn.out_proj.weight.detach().to(device=device, dtype=dtype).contiguous()
+        p.b_o = _f32(blk.attn.out_proj.bias, device)
+        p.w_fc = blk.mlp.c_fc.weight.detach().to(device=device, dtype=dtype).contiguous()
+        p.b_fc = _f32(blk.mlp.c_fc.bias, device)
+        p.w_pr = blk.mlp.c_proj.weight.detach().to(device=device, dtype=dtype).contiguous()
+        p.b_pr = _f32(blk.mlp.c_proj.bias, device)
+        out.append(p)
+    return out
+
+
+class _Workspace:
+    """Activation buffers of one tower for one (batch, tokens) shape."""
+
+    def __init__(self, rows: int, d: int, dtype: torch.dtype, device):
+        self.h = torch.empty((rows, d), dtype=dtype, device=device)
+        self.qkv = torch.empty((rows, 3 * d), dtype=dtype, device=device)
+        self.ctx = torch.empty((rows, d), dtype=dtype, device=device)
+        self.u = torch.empty((rows, 4 * d), dtype=dtype, device=device)
+
+
+def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
+               taps: Optional[dict] = None) -> torch.Tensor:
+    """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228)."""
+    for i, p in enumerate(blocks):
+        ops.layernorm(x, p.ln1_w, p.ln1_b, out=ws.h)
+        ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)
+        ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
+        if taps is not None:
+            taps[f"block{i}.ln_1"] = ws.h.float().clone()
+            taps[f"block{i}.attn_ctx"] = ws.ctx.float().clone()
+        ops.gemm(ws.ctx, p.w_o, p.b_o, residual=x, out=x)
+        ops.layernorm(x, p.ln2_w, p.ln2_b, out=ws.h)
+        ops.gemm(ws.h, p.w_fc, p.b_fc, act=ACT_QUICKGELU, out=ws.u)
+        if taps is not None:
+            taps[f"block{i}.after_attn"] = x.float().clone()
+            taps[f"block{i}.ln_2"] = ws.h.float().clone()
+            taps[f"block{i}.gelu"] = ws.u.float().clone()
+        ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
+        if taps is not None:
+            taps[f"block{i}.out"] = x.float().clone()
+    return x
+
+
+class VisionEngine:
+    """VisionTransformer.forward (clip/model.py:259-276) as a HIP kernel sequence."""
+
+    def __init__(self, visual, dtype: torch.dtype, device):
+        self.dtype, self.device = dtype, device
+        w = visual.conv1.weight.detach()
+        self.width, _, self.patch, _ = w.shape
+        self.resolution = int(visual.input_resolution)
+        self.heads = self.width // 64
+        grid = self.resolution // self.patch
+        self.tokens = grid * grid + 1
+        k = 3 * self.patch * self.patch
+        align = 32 if dtype == torch.float32 else 64
+        kp = (k + align - 1) // align * align
+        wp = torch.zeros((self.width, kp), dtype=dtype, device=device)
+        wp[:, :k] = w.reshape(self.width, k).to(device=device, dtype=dtype)
+        self.wp = wp
+        self.cls = _f32(visual.class_embedding, device)
+        self.pos = _f32(visual.positional_embedding, device)
+        self.ln_pre_w, self.ln_pre_b = _f32(visual.ln_pre.weight, device), _f32(visual.ln_pre.bias, device)
+        self.ln_post_w, self.ln_post_b = _f32(visual.ln_post.weight, device), _f32(visual.ln_post.bias, device)
+        self.proj = visual.proj.detach().to(device=device, dtype=dtype).contiguous()
+        self.blocks = pack_blocks(visual.transformer.resblocks, dtype, device)
+        self._ws: Dict[int, tuple] = {}
+
+    def _workspace(self, batch: int):
+        if batch not in self._ws:
+            self._ws.clear()  # one live batch shape: HBM is large but bench shapes are few
+            rows = batch * self.tokens
+            self._ws[batch] = (
+                _Workspace(rows, self.width, self.dtype, self.device),
+                torch.empty((rows, self.width), dtype=self.dtype, device=self.device),
+                ops.patch_embed_workspace(batch, self.resolution, self.patch, self.dtype, self.device),
+                (torch.arange(batch, device=self.device, dtype=torch.int64) * self.tokens).contiguous(),
+            )
+        return self._ws[batch]
+
+    def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.resolution or image.shape[3] != self.resolution:
+            raise ValueError(f"image must be [B,3,{self.resolution},{self.resolution}], got {tuple(image.shape)}")
+        batch = image.shape[0]
+        ws, x, patch_ws, cls_rows = self._workspace(batch)
+        image = image.contiguous()
+        ops.patch_embed(image, self.wp, self.cls, self.pos, self.patch, self.dtype, workspace=patch_ws,
+                        out=x.view(batch, self.tokens, self.width))
+        if taps is not None:
+            taps["embed"] = x.float().clone()
+        ops.layernorm(x, self.ln_pre_w, self.ln_pre_b, out=x)
+        if taps is not None:
+            taps["ln_pre"] = x.float().clone()
+        run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps)
+        # ln_post on the class token only, then @ proj (clip/model.py:271-274); fp32 features
+        return ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)
+
+
+class TextEngine:
+    """CLIP.encode_text / TextEncoder.forward (clip/model.py:379-392; trainers/Caption_distill_double.py:82-101)."""
+
+    def __init__(self, clip_model, dtype: torch.dtype, device):
+        self.dtype, self.device = dtype, device
+        self.width = clip_model.ln_final.weight.shape[0]
+        self.heads = self.width // 64
+        self.table = _f32(clip_model.token_embedding.weight, device)
+        self.pos = _f32(clip_model.positional_embedding, device)
+        self.ln_w, self.ln_b = _f32(clip_model.ln_final.weight, device), _f32(clip_model.ln_final.bias, device)
+        self.proj = clip_model.text_projection.detach().to(device=device, dtype=dtype).contiguous()
+        self.proj_t = self.proj.t().contiguous()  # [E, d] nn.Linear layout for the if_sequence GEMM
+        self.blocks = pack_blocks(clip_model.transformer.resblocks, dtype, device)
+        self._ws: Dict[tuple, _Workspace] = {}
+
+    def _workspace(self, n: int, t: int) -> _Workspace:
+        key = (n, t)
+        if key not in self._ws:
+            if len(self._ws) > 4:
+                self._ws.clear()
+            self._ws[key] = _Workspace(n * t, self.width, self.dtype, self.device)
+        return self._ws[key]
+
+    def _tower(self, x: torch.Tensor, n: int, t: int, taps: Optional[dict]):
+        return run_blocks(x.view(n * t, self.width), self.blocks, self._workspace(n, t), n, t, self.heads, True, taps)
+
+    def _pool(self, x: torch.Tensor, tokens: torch.Tensor, n: int, t: int, if_sequence: bool):
+        if if_sequence:
+            h = ops.layernorm(x, self.ln_w, self.ln_b)
+            return ops.gemm(h, self.proj_t, out_dtype=torch.float32).view(n, t, -1)
+        _, flat = ops.eot_index(tokens.to(self.device).contiguous())
+        return ops.gather_ln_proj(x, flat, self.ln_w, self.ln_b, self.proj)
+
+    def encode_tokens(self, tokens: torch.Tensor, if_sequence: bool = False, taps: Optional[dict] = None):
+        tokens = tokens.to(self.device).contiguous()
+        n, t = tokens.shape
+        x = ops.embed_tokens(tokens, self.table, self.pos, self.dtype)
+        x = self._tower(x, n, t, taps)
+        return self._pool(x, tokens, n, t, if_sequence)
+
+    def encode_prompts(self, prompts: torch.Tensor, tokenized_prompts: torch.Tensor, if_sequence: bool = False,
+                       taps: Optional[dict] = None):
+        n, t, _ = prompts.shape
+        x = ops.add_pos(prompts.to(device=self.device, dtype=torch.float32), self.pos, self.dtype)
+        x = self._tower(x, n, t, taps)
+        return self._pool(x, tokenized_prompts, n, t, if_sequence)

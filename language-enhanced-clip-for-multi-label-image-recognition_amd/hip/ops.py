@@ -1,0 +1,215 @@
+"""Tensor-level wrappers over the C ABI: validate torch tensors, pass raw pointers + the current HIP stream.
+
+PyTorch is plumbing here (device memory, streams); every arithmetic step is a kernel in
+``csrc/*.hip``.  Each wrapper mirrors one ``leclip_*_fwd`` entry point of ``include/leclip_hip.h``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _capi
+from ._capi import ACT_NONE, ACT_QUICKGELU, MASK_CAUSAL, MASK_NONE
+
+_DT = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.bfloat16: _capi.BF16}
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    try:
+        return _DT[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}; the HIP path computes in float32, float16 or bfloat16") from None
+
+
+def _dev(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} is on {t.device}: the CLIP scoring path runs only on a HIP device "
+                           f"(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+    return t
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rows2d(t: torch.Tensor, name: str):
+    """View a [..., d] tensor as rows; returns (rows, d, leading dimension)."""
+    _dev(t, name)
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: last dimension must be contiguous")
+    if t.dim() == 1:
+        return 1, t.shape[0], t.shape[0]
+    if t.dim() > 2 and not t.is_contiguous():
+        raise ValueError(f"{name}: tensors with more than 2 dims must be contiguous")
+    rows = t.numel() // t.shape[-1]
+    ld = t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+    return rows, t.shape[-1], ld
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5,
+              out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    rows, dim, ldx = _rows2d(x, "x")
+    if out is None:
+        out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
+    _, _, ldy = _rows2d(out, "out")
+    assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == dim == beta.numel()
+    _capi.check(_capi.load().leclip_layernorm_fwd(_ptr(x), _ptr(_dev(gamma, "gamma")), _ptr(_dev(beta, "beta")), _ptr(out),
+                                                  rows, dim, ldx, ldy, eps, dtype_code(x.dtype), dtype_code(out.dtype),
+                                                  _stream()), "layernorm")
+    return out
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         act: int = ACT_NONE, out_dtype: Optional[torch.dtype] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(a @ w.T + bias) + residual ; a [..., K], w [N, K] (nn.Linear layout)."""
+    m, k, lda = _rows2d(a, "a")
+    n, kw, ldw = _rows2d(w, "w")
+    if k != kw or a.dtype != w.dtype:
+        raise ValueError(f"gemm: a [.., {k}] {a.dtype} vs w [{n}, {kw}] {w.dtype}")
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (n,), dtype=out_dtype or a.dtype, device=a.device)
+    mo, no, ldy = _rows2d(out, "out")
+    assert (mo, no) == (m, n)
+    ldr = 0
+    rdt = _capi.F32
+    if residual is not None:
+        mr, nr, ldr = _rows2d(residual, "residual")
+        assert (mr, nr) == (m, n)
+        rdt = dtype_code(residual.dtype)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() == n
+        _dev(bias, "bias")
+    _capi.check(_capi.load().leclip_gemm_bias_act_res_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), m, n, k,
+                                                          lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
+                                                          dtype_code(out.dtype), _stream()), "gemm")
+    return out
+
+
+def patch_embed_workspace(batch: int, resolution: int, patch: int, w_dtype: torch.dtype, device) -> torch.Tensor:
+    nbytes = _capi.load().leclip_patch_embed_workspace_bytes(batch, resolution, patch, dtype_code(w_dtype))
+    if nbytes < 0:
+        raise ValueError("patch_embed: bad geometry")
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, pos: torch.Tensor, patch: int,
+                x_dtype: torch.dtype, workspace: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+    _dev(image, "image")
+    b, c, r, r2 = image.shape
+    if c != 3 or r != r2 or not image.is_contiguous():
+        raise ValueError("patch_embed: image must be contiguous [B,3,R,R]")
+    width = wp.shape[0]
+    t = (r // patch) ** 2 + 1
+    assert pos.shape == (t, width) and pos.dtype == torch.float32 and class_emb.dtype == torch.float32
+    if workspace is None:
+        workspace = patch_embed_workspace(b, r, patch, wp.dtype, image.device)
+    if out is None:
+        out = torch.empty((b, t, width), dtype=x_dtype, device=image.device)
+    _capi.check(_capi.load().leclip_patch_embed_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(out), b, r,
+                                                    patch, width, dtype_code(image.dtype), dtype_code(wp.dtype),
+                                                    dtype_code(out.dtype), _ptr(workspace), _stream()), "patch_embed")
+    return out
+
+
+def attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, causal: bool = False,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    rows, width3, ld = _rows2d(qkv, "qkv")
+    d = heads * 64
+    if rows != batch * tokens or width3 != 3 * d:
+        raise ValueError(f"attention: qkv {tuple(qkv.shape)} vs B={batch} T={tokens} heads={heads}")
+    if out is None:
+        out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
+    _, _, ldo = _rows2d(out, "out")
+    _capi.check(_capi.load().leclip_attention_fwd(_ptr(qkv), _ptr(out), batch, tokens, heads, 64, ld, ldo,
+                                                  MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype),
+                                                  _stream()), "attention")
+    return out
+
+
+def gather_ln_proj(x: torch.Tensor, row_index: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor,
+                   proj: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    rows, dim, ldx = _rows2d(x, "x")
+    assert proj.dim() == 2 and proj.shape[0] == dim and proj.is_contiguous()
+    n = rows if row_index is None else row_index.numel()
+    if row_index is not None:
+        assert row_index.dtype == torch.int64 and row_index.is_contiguous()
+        _dev(row_index, "row_index")
+    out = torch.empty((n, proj.shape[1]), dtype=torch.float32, device=x.device)
+    _capi.check(_capi.load().leclip_gather_ln_proj_fwd(_ptr(x), _ptr(row_index), _ptr(_dev(gamma, "gamma")), _ptr(_dev(beta, "beta")),
+                                                       _ptr(_dev(proj, "proj")), _ptr(out), n, dim, proj.shape[1], ldx, eps,
+                                                       dtype_code(x.dtype), dtype_code(proj.dtype), _stream()),
+                "gather_ln_proj")
+    return out
+
+
+def l2norm_logits(img: torch.Tensor, txt: torch.Tensor, scale: float) -> torch.Tensor:
+    _dev(img, "image_features"), _dev(txt, "text_features")
+    if img.dtype != torch.float32 or txt.dtype != torch.float32:
+        raise TypeError("l2norm_logits: features must be float32")
+    img, txt = img.contiguous(), txt.contiguous()
+    b, d = img.shape
+    c, d2 = txt.shape
+    assert d == d2
+    out = torch.empty((b, c), dtype=torch.float32, device=img.device)
+    _capi.check(_capi.load().leclip_l2norm_logits_fwd(_ptr(img), _ptr(txt), _ptr(out), b, c, d, float(scale), _stream()),
+                "l2norm_logits")
+    return out
+
+
+def embed_tokens(tokens: torch.Tensor, table: torch.Tensor, pos: torch.Tensor, x_dtype: torch.dtype) -> torch.Tensor:
+    _dev(tokens, "tokens")
+    assert tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.is_contiguous()
+    assert table.dtype == torch.float32 and pos.dtype == torch.float32 and table.is_contiguous() and pos.is_contiguous()
+    n, t = tokens.shape
+    dim = table.shape[1]
+    assert pos.shape[0] >= t and pos.shape[1] == dim
+    out = torch.empty((n, t, dim), dtype=x_dtype, device=tokens.device)
+    _capi.check(_capi.load().leclip_embed_tokens_fwd(_ptr(tokens), _ptr(_dev(table, "table")), _ptr(_dev(pos, "pos")), _ptr(out), n, t,
+                                                     dim, table.shape[0], dtype_code(x_dtype), _stream()), "embed_tokens")
+    return out
+
+
+def prompt_assemble(prefix: torch.Tensor, ctx: torch.Tensor, suffix: torch.Tensor, pos: Optional[torch.Tensor],
+                    x_dtype: torch.dtype) -> torch.Tensor:
+    for name, t in (("prefix", prefix), ("ctx", ctx), ("suffix", suffix)):
+        _dev(t, name)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"prompt_assemble: {name} must be contiguous float32")
+    n_cls, one, dim = prefix.shape
+    per_class = ctx.dim() == 3
+    n_ctx = ctx.shape[-2]
+    t = 1 + n_ctx + suffix.shape[1]
+    assert one == 1 and suffix.shape[0] == n_cls and ctx.shape[-1] == dim
+    if pos is not None:
+        assert pos.dtype == torch.float32 and pos.shape[0] >= t and pos.is_contiguous()
+    out = torch.empty((n_cls, t, dim), dtype=x_dtype, device=prefix.device)
+    _capi.check(_capi.load().leclip_prompt_assemble_fwd(_ptr(prefix), _ptr(ctx), _ptr(suffix), _ptr(pos), _ptr(out), n_cls, n_ctx, t,
+                                                        dim, int(per_class), dtype_code(x_dtype), _stream()), "prompt_assemble")
+    return out
+
+
+def add_pos(x: torch.Tensor, pos: torch.Tensor, x_dtype: torch.dtype) -> torch.Tensor:
+    _dev(x, "prompts")
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and x.dim() == 3 and pos.dtype == torch.float32 and pos.is_contiguous()
+    n, t, dim = x.shape
+    out = torch.empty((n, t, dim), dtype=x_dtype, device=x.device)
+    _capi.check(_capi.load().leclip_add_pos_fwd(_ptr(x), _ptr(_dev(pos, "pos")), _ptr(out), n, t, dim, dtype_code(x_dtype), _stream()),
+                "add_pos")
+    return out
+
+
+def eot_index(tokens: torch.Tensor):
+    """(argmax over the token axis, flat row n*T + argmax) - both int64 device tensors."""
+    _dev(tokens, "tokens")
+    assert tokens.dtype == torch.int64 and tokens.dim() == 2 and tokens.is_contiguous()
+    n, t = tokens.shape
+    eot = torch.empty(n, dtype=torch.int64, device=tokens.device)
+    flat = torch.empty(n, dtype=torch.int64, device=tokens.device)
+    _capi.check(_capi.load().leclip_eot_index_fwd(_ptr(tokens), _ptr(eot), _ptr(flat), n, t, _stream()), "eot_index")
+    return eot, flat

@@ -241,7 +241,7 @@ def make_state_dict(arch: ClipArch, seed: int = 0, dist: str = "cond", towers: s
         a = make_tensor(seed, name, spec)
         if as_torch:
             import torch
-            sd[name] = torch.from_numpy(np.ascontiguousarray(a))
+            sd[name] = torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)
         else:
             sd[name] = a
     return sd

@@ -1,0 +1,281 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the committed golden vectors.
+
+Tolerances (north-star: "within 1e-3 fp32, label-index outputs bit-exact"):
+* fp32 mode  - logits <= 1e-3 abs against the golden vectors of the reference forward, top-5 indices exact;
+* fp16/bf16  - logits within the measured low-precision band (fp16 3e-3, bf16 3e-2 at scale 4.0), argmax exact
+  on samples whose oracle top-1 margin exceeds twice that band.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from leclip_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.float16, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from leclip_amd.hip import ops as _ops, _capi
+    _capi.load()  # fails loudly if the library is missing
+    return _ops
+
+
+def _rand(shape, seed, std=1.0):
+    return torch.from_numpy(synth.normal(seed, "t", shape, std=std))
+
+
+def _tol(dt, f32=2e-5, f16=4e-3, bf16=3e-2):
+    return {torch.float32: f32, torch.float16: f16, torch.bfloat16: bf16}[dt]
+
+
+# ----------------------------------------------------------------------------------------------- per-op parity
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("dim", [64, 128, 512, 768, 1024])
+def test_layernorm(ops, dt, dim):
+    from oracle import clip_oracle as co
+    x = _rand((37, dim), 1, 3.0) + 0.5
+    g, b = _rand((dim,), 2) * 0.1 + 1, _rand((dim,), 3) * 0.1
+    xq = x.to(dt)
+    ref = co.layer_norm(xq.float(), g, b)
+    for odt in (dt, torch.float32):
+        y = ops.layernorm(xq.to(DEV), g.to(DEV), b.to(DEV), out_dtype=odt)
+        assert y.dtype == odt
+        np.testing.assert_allclose(y.float().cpu().numpy(), ref.numpy(), atol=_tol(odt, 2e-5, 4e-3, 3e-2), rtol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("shape", [(1, 128, 64), (197, 768, 768), (1000, 256, 3072), (130, 384, 192)])
+@pytest.mark.parametrize("epi", ["plain", "bias_gelu", "bias_res"])
+def test_gemm(ops, dt, shape, epi):
+    from leclip_amd.hip import ops as o
+    m, n, k = shape
+    a, w = _rand((m, k), 4).to(dt), _rand((n, k), 5, k ** -0.5).to(dt)
+    bias, res = _rand((n,), 6), _rand((m, n), 7).to(dt)
+    ref = a.double() @ w.double().t()
+    kw = {}
+    if epi != "plain":
+        ref = ref + bias.double()
+        kw["bias"] = bias.to(DEV)
+    if epi == "bias_gelu":
+        ref = ref * torch.sigmoid(1.702 * ref)
+        kw["act"] = o.ACT_QUICKGELU
+    if epi == "bias_res":
+        ref = ref + res.double()
+        kw["residual"] = res.to(DEV)
+    y = ops.gemm(a.to(DEV), w.to(DEV), **kw)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-6, 2e-3, 1.2e-2) * scale, rtol=0)
+    y32 = ops.gemm(a.to(DEV), w.to(DEV), out_dtype=torch.float32, **kw)
+    np.testing.assert_allclose(y32.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-6, 1e-3, 6e-3) * scale, rtol=0)
+
+
+def test_gemm_inplace_residual_and_errors(ops):
+    from leclip_amd.hip._capi import HipKernelError
+    a, w = _rand((300, 128), 8).bfloat16().to(DEV), _rand((128, 128), 9, 0.1).bfloat16().to(DEV)
+    x = _rand((300, 128), 10).bfloat16().to(DEV)
+    ref = ops.gemm(a, w, residual=x)
+    out = ops.gemm(a, w, residual=x, out=x)
+    assert out.data_ptr() == x.data_ptr() and torch.equal(out, ref)
+    with pytest.raises(HipKernelError):     # N not a multiple of 128 for 16-bit operands
+        ops.gemm(a, _rand((100, 128), 1).bfloat16().to(DEV))
+    with pytest.raises(RuntimeError):       # CPU tensor: no fallback
+        ops.gemm(a.cpu(), w.cpu())
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("cfg", [(2, 197, 12, False), (3, 77, 8, True), (2, 17, 2, False), (1, 50, 1, True), (2, 224, 1, False),
+                                 (1, 1, 1, True)])
+def test_attention(ops, dt, cfg):
+    b, t, h, causal = cfg
+    d = 64 * h
+    qkv = _rand((b * t, 3 * d), 11).to(dt)
+    q, k, v = [z.reshape(b, t, h, 64).transpose(1, 2).double() for z in qkv.float().split(d, dim=-1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.triu(torch.full((t, t), float("-inf"), dtype=torch.float64), 1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b * t, d)
+    y = ops.attention(qkv.to(DEV), b, t, h, causal)
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-5, 4e-3, 2.5e-2), rtol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gather_ln_proj_and_logits(ops, dt):
+    from oracle import clip_oracle as co
+    x = _rand((40, 768), 12, 2.0).to(dt)
+    idx = torch.tensor([0, 39, 7, 7, 13], dtype=torch.int64)
+    g, b, proj = _rand((768,), 13) * 0.1 + 1, _rand((768,), 14) * 0.1, _rand((768, 512), 15, 768 ** -0.5).to(dt)
+    ref = co.layer_norm(x.float()[idx], g, b) @ proj.float()
+    y = ops.gather_ln_proj(x.to(DEV), idx.to(DEV), g.to(DEV), b.to(DEV), proj.to(DEV))
+    np.testing.assert_allclose(y.cpu().numpy(), ref.numpy(), atol=3e-5 * float(ref.abs().max()) + 1e-5, rtol=0)
+    fi, ft = _rand((9, 512), 16), _rand((80, 512), 17)
+    lg = ops.l2norm_logits(fi.to(DEV), ft.to(DEV), 4.0)
+    np.testing.assert_allclose(lg.cpu().numpy(), co.cosine_logits(fi, ft, 4.0).numpy(), atol=2e-6, rtol=0)
+
+
+def test_embedding_kernels(ops, golden_dir):
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    toks = torch.from_numpy(t["tokens_ctx16"])
+    table, pos = _rand((49408, 128), 18), _rand((77, 128), 19, 0.01)
+    x = ops.embed_tokens(toks.to(DEV), table.to(DEV), pos.to(DEV), torch.float32)
+    assert torch.equal(x.cpu(), table[toks] + pos)
+    eot, flat = ops.eot_index(toks.to(DEV))
+    assert torch.equal(eot.cpu(), toks.argmax(-1)) and torch.equal(flat.cpu(), torch.arange(80) * 77 + toks.argmax(-1))
+    emb = table[toks]
+    ctx = _rand((16, 128), 20, 0.02)
+    ref = torch.cat([emb[:, :1], ctx.expand(80, -1, -1), emb[:, 17:]], 1)
+    out = ops.prompt_assemble(emb[:, :1].contiguous().to(DEV), ctx.to(DEV), emb[:, 17:].contiguous().to(DEV), None, torch.float32)
+    assert torch.equal(out.cpu(), ref)
+    ctx_c = _rand((80, 16, 128), 21, 0.02)
+    out = ops.prompt_assemble(emb[:, :1].contiguous().to(DEV), ctx_c.to(DEV), emb[:, 17:].contiguous().to(DEV), pos.to(DEV), torch.float32)
+    assert torch.equal(out.cpu(), torch.cat([emb[:, :1], ctx_c, emb[:, 17:]], 1) + pos)
+    assert torch.equal(ops.add_pos(ref.to(DEV), pos.to(DEV), torch.float32).cpu(), ref + pos)
+    # ties: argmax returns the first maximum, like torch
+    tie = torch.tensor([[5, 9, 9, 1], [0, 0, 0, 0]], dtype=torch.int64)
+    assert torch.equal(ops.eot_index(tie.to(DEV))[0].cpu(), tie.argmax(-1))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("geom", [(32, 8, 128), (224, 16, 768), (28, 14, 128)])
+def test_patch_embed(ops, dt, geom):
+    from oracle import clip_oracle as co
+    r, p, width = geom
+    img = _rand((3, 3, r, r), 22)
+    w = _rand((width, 3, p, p), 23, (3 * p * p) ** -0.5).to(dt)
+    cls, pos = _rand((width,), 24), _rand(((r // p) ** 2 + 1, width), 25)
+    sd = {"visual.conv1.weight": w.float(), "visual.class_embedding": cls, "visual.positional_embedding": pos}
+    ref = co.patch_embed(img.to(dt).float(), sd)
+    k = 3 * p * p
+    al = 32 if dt == torch.float32 else 64
+    kp = (k + al - 1) // al * al
+    wp = torch.zeros((width, kp), dtype=dt)
+    wp[:, :k] = w.reshape(width, k)
+    x = ops.patch_embed(img.to(DEV), wp.to(DEV), cls.to(DEV), pos.to(DEV), p, dt)
+    np.testing.assert_allclose(x.float().cpu().numpy(), ref.numpy(), atol=_tol(dt, 1e-5, 6e-3, 5e-2), rtol=0)
+
+
+# --------------------------------------------------------------------------------- towers against the oracle / golden
+def _build(arch, seed, dist, dtype):
+    from leclip_amd.clip import build_model, convert_weights
+    m = build_model(synth.make_state_dict(arch, seed=seed, dist=dist))
+    m.float()
+    if dtype != torch.float32:
+        convert_weights(m, dtype)
+    return m.to(DEV)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_tiny_per_stage(ops, golden_dir, dt):
+    g = np.load(os.path.join(golden_dir, "tiny_stages.npz"))
+    m = _build(synth.TINY, 1, "cond", dt)
+    taps = {}
+    feat = m.visual(torch.from_numpy(g["images"]).to(DEV), taps)
+    tol = _tol(dt, 2e-4, 3e-2, 2.5e-1)
+    np.testing.assert_allclose(taps["ln_pre"].cpu().numpy().reshape(g["v.ln_pre"].shape), g["v.ln_pre"], atol=tol, rtol=tol)
+    for i in range(synth.TINY.vision_layers):
+        for k in ("ln_1", "ln_2", "gelu", "out"):
+            got = taps[f"block{i}.{k}"].cpu().numpy().reshape(g[f"v.block{i}.{k}"].shape)
+            np.testing.assert_allclose(got, g[f"v.block{i}.{k}"], atol=tol, rtol=tol, err_msg=f"block{i}.{k}")
+    np.testing.assert_allclose(feat.cpu().numpy(), g["v.feat"], atol=tol, rtol=tol)
+    toks = torch.from_numpy(g["tokens"]).to(DEV)
+    taps = {}
+    tf = m.text_engine(torch.device(DEV)).encode_tokens(toks, taps=taps)
+    for i in range(synth.TINY.transformer_layers):
+        for k in ("ln_1", "ln_2", "gelu", "out"):
+            got = taps[f"block{i}.{k}"].cpu().numpy().reshape(g[f"t.block{i}.{k}"].shape)
+            np.testing.assert_allclose(got, g[f"t.block{i}.{k}"], atol=tol, rtol=tol, err_msg=f"text block{i}.{k}")
+    np.testing.assert_allclose(tf.cpu().numpy(), g["t.feat"], atol=tol, rtol=tol)
+    lpi, lpt = m(torch.from_numpy(g["images"]).to(DEV), toks)
+    ltol = _tol(dt, 1e-3, 2e-2, 1.5e-1)  # scale exp(logit_scale) = 14.3
+    np.testing.assert_allclose(lpi.cpu().numpy(), g["logits_per_image"], atol=ltol, rtol=0)
+    np.testing.assert_allclose(lpt.cpu().numpy(), g["logits_per_text"], atol=ltol, rtol=0)
+
+
+def _margin_ok(ref_logits, band):
+    s = np.sort(ref_logits, axis=1)
+    return (s[:, -1] - s[:, -2]) > 2 * band
+
+
+@pytest.mark.parametrize("dist", ["cond", "default"])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_vitb16_cfg1_golden(ops, golden_dir, dt, dist):
+    """BASELINE config 1 (ViT-B/16, 80 prompts, B=8) against the reference forward's golden outputs."""
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg1.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    m = _build(synth.VIT_B16, 0, dist, dt)
+    img = torch.from_numpy(synth.make_images(8, 224, seed=1234)).to(DEV)
+    toks = torch.from_numpy(t["tokens_photo"]).to(DEV)
+    lpi, _ = m(img, toks)
+    lpi = lpi.cpu().numpy()
+    ref = g[dist + ".logits_clip"]
+    band = _tol(dt, 1e-3, 1.5e-2, 1.2e-1)  # scale 14.29: cosine error x 14.29
+    np.testing.assert_allclose(lpi, ref, atol=band, rtol=0)
+    if dt == torch.float32:
+        assert np.array_equal(np.argsort(-lpi, axis=1, kind="stable")[:, :5], g[dist + ".top5_clip"])
+        fi = m.encode_image(img).cpu().numpy()
+        np.testing.assert_allclose(fi, g[dist + ".image_features"], atol=1e-3, rtol=1e-3)
+    else:
+        ok = _margin_ok(ref, band)
+        assert np.array_equal(lpi.argmax(1)[ok], ref.argmax(1)[ok])
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_custom_clip_golden(ops, golden_dir, dt):
+    """CustomCLIP (learnable 16-token context, x4.0 cosine logits), image branch and caption-as-image branch."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import CustomCLIP
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg1.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    m = _build(synth.VIT_B16, 0, "cond", dt).cpu()
+    cc = CustomCLIP(get_cfg_default(), coco_object_categories, m)
+    with torch.no_grad():
+        cc.prompt_learner.ctx.copy_(torch.from_numpy(synth.make_ctx(16, 512, seed=0)))
+    cc.to(DEV).eval()
+    assert np.array_equal(cc.tokenized_prompts.numpy(), t["tokens_ctx16"])
+    img = torch.from_numpy(synth.make_images(8, 224, seed=1234)).to(DEV)
+    with torch.no_grad():
+        logits, a, b, c = cc(img, if_test=True)
+        lcap = cc(None, torch.from_numpy(t["tokens_photo"][:6]).to(DEV))[0]
+        prompts = cc.prompt_learner()[0]
+    assert a is None and b is None and c is None and logits.shape == (8, 80)
+    band = _tol(dt, 1e-3, 4e-3, 3.5e-2)
+    ref = g["cond.logits_custom_ctx16"]
+    np.testing.assert_allclose(logits.cpu().numpy(), ref, atol=band, rtol=0)
+    np.testing.assert_allclose(lcap.cpu().numpy(), g["cond.logits_custom_captions"], atol=band, rtol=0)
+    if dt == torch.float32:
+        assert np.array_equal(np.argsort(-logits.cpu().numpy(), axis=1, kind="stable")[:, :5], g["cond.top5_custom_ctx16"])
+    else:
+        ok = _margin_ok(ref, band)
+        assert np.array_equal(logits.cpu().numpy().argmax(1)[ok], ref.argmax(1)[ok])
+    # PromptLearner.forward()[0] is exactly cat(prefix, ctx, suffix)
+    sd_tab = m.token_embedding.weight.detach().float().cpu()
+    emb = sd_tab[torch.from_numpy(t["tokens_ctx16"])]
+    want = torch.cat([emb[:, :1], cc.prompt_learner.ctx.detach().cpu().expand(80, -1, -1), emb[:, 17:]], 1)
+    assert torch.equal(prompts.cpu(), want)
+
+
+def test_full_batch_properties(ops):
+    """BASELINE config 2 size (B=256, bf16): batch invariance - an image's logits do not depend on its batch -
+    and shard consistency (rows of the B=256 run equal the rows of two B=128 runs), bit for bit."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import CustomCLIP
+    m = _build(synth.VIT_B16, 0, "cond", torch.bfloat16).cpu()
+    cc = CustomCLIP(get_cfg_default(), coco_object_categories, m).to(DEV).eval()
+    img = torch.from_numpy(synth.make_images(256, 224, seed=77)).to(DEV)
+    with torch.no_grad():
+        full = cc(img, if_test=True)[0].clone()
+        lo = cc(img[:128].contiguous(), if_test=True)[0].clone()
+        hi = cc(img[128:].contiguous(), if_test=True)[0].clone()
+        one = cc(img[200:201].contiguous(), if_test=True)[0].clone()
+    assert torch.isfinite(full).all()
+    assert torch.equal(full[:128], lo) and torch.equal(full[128:], hi) and torch.equal(full[200:201], one)
+    assert float(full.abs().max()) <= 4.0 + 1e-4   # |cos| <= 1 scaled by 4

@@ -1,0 +1,212 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, and the host logic around the
+kernels (architecture inference, state-dict round trip, tokenizer, prompt buffers, config/registry, checkpoints,
+evaluator) behaves like the reference's.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from leclip_amd import synth
+from leclip_amd.config import get_cfg_default
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_BPE = "/root/reference/project/my_code/clip/bpe_simple_vocab_16e6.txt.gz"
+
+
+def test_library_exports_every_declared_symbol():
+    from leclip_amd.hip import _capi
+    hdr = open(os.path.join(ROOT, "include", "leclip_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(leclip_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert os.path.exists(_capi.LIB_PATH), "build the library first: python __graft_entry__.py build"
+    lib = ctypes.CDLL(_capi.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/leclip_hip.h but not exported"
+    assert declared == set(_capi.SIGNATURES), "ctypes binding and header disagree"
+    assert _capi.load().leclip_abi_version() == _capi.ABI_VERSION
+    assert _capi.load().leclip_strerror(-2) == b"unsupported shape or dtype"
+    assert _capi.load().leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) in (b"gemm_tn_128x128x64", b"gemm_tn_256x256x64")
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from leclip_amd.hip import _capi
+    monkeypatch.setattr(_capi, "_lib", None)
+    monkeypatch.setenv("LECLIP_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(_capi.HipLibraryError):
+        _capi.load()
+
+
+def test_cpu_tensors_are_refused():
+    from leclip_amd.clip import build_model
+    from leclip_amd.hip import ops
+    m = build_model(synth.make_state_dict(synth.TINY, seed=1)).float()
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.encode_image(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="HIP device"):
+        m.encode_text(torch.zeros(1, 77, dtype=torch.long))
+    with pytest.raises(RuntimeError):
+        ops.layernorm(torch.zeros(4, 64), torch.ones(64), torch.zeros(64))
+
+
+def test_generator_is_deterministic_and_counter_based():
+    a = synth.normal(3, "w", (1000,))
+    b = synth.normal(3, "w", (2000,))
+    assert np.array_equal(a, b[:1000]) and not np.array_equal(a, synth.normal(4, "w", (1000,)))
+    assert abs(float(b.mean())) < 0.1 and abs(float(b.std()) - 1) < 0.1
+    imgs = synth.make_images(4, 32, seed=5)
+    assert np.array_equal(imgs[2:], synth.make_images(2, 32, seed=5, start=2))   # shards of a global batch agree
+    sd = synth.make_state_dict(synth.TINY, seed=1, as_torch=False)
+    for k, v in sd.items():
+        assert np.array_equal(v, v.astype(np.float16).astype(np.float32)), k     # fp16-representable
+
+
+def test_build_model_arch_inference_and_state_dict_round_trip():
+    from leclip_amd.clip import build_model
+    from leclip_amd.clip.model import arch_from_state_dict
+    for arch in (synth.TINY,):
+        sd = synth.make_state_dict(arch, seed=2)
+        sd_meta = dict(sd, input_resolution=torch.tensor(arch.image_resolution), context_length=torch.tensor(77),
+                       vocab_size=torch.tensor(arch.vocab_size))
+        got = arch_from_state_dict(sd_meta)
+        want = arch.to_dict()
+        assert got == want
+        m = build_model(sd_meta)
+        assert not m.training and m.dtype == torch.float16 and m.visual.input_resolution == arch.image_resolution
+        assert m.ln_final.weight.dtype == torch.float32 and m.token_embedding.weight.dtype == torch.float32
+        assert m.visual.positional_embedding.dtype == torch.float32          # convert_weights leaves these in fp32
+        assert m.transformer.resblocks[0].attn.in_proj_weight.dtype == torch.float16
+        out = m.state_dict()
+        assert set(out) == set(sd)
+        for k in sd:
+            assert torch.equal(out[k].float(), sd[k]), k                    # values are fp16-representable
+    # ViT-B/16 / ViT-L/14@336 shape inference from specs only (no tensors materialised)
+    for arch in (synth.VIT_B16, synth.VIT_L14_336):
+        fake = {k: torch.empty(spec[0], device="meta") for k, spec in synth.state_dict_specs(arch).items()}
+        assert arch_from_state_dict(fake) == arch.to_dict()
+    with pytest.raises(NotImplementedError):
+        arch_from_state_dict({"visual.layer1.0.conv1.weight": torch.zeros(1)})
+
+
+def test_tokenize_matches_reference_fixture(golden_dir):
+    from leclip_amd.clip import clip as C
+    g = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    names = [str(c) for c in g["classnames"]]
+    from leclip_amd.datasets import coco_object_categories, prompt_template
+    assert names == coco_object_categories
+    toks = C.tokenize([prompt_template.format(c) for c in names])
+    assert toks.dtype == torch.int64 and np.array_equal(toks.numpy(), g["tokens_photo"])
+    assert np.array_equal(toks.argmax(-1).numpy(), g["eot_photo"])
+    with pytest.raises(RuntimeError):
+        C.tokenize("person " * 100) if C.get_tokenizer() is not None else (_ for _ in ()).throw(RuntimeError())
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BPE), reason="BPE merge table only available next to the reference")
+def test_bpe_tokenizer_against_reference_vectors(golden_dir, monkeypatch):
+    from leclip_amd.clip import clip as C
+    from leclip_amd.clip.simple_tokenizer import SimpleTokenizer
+    tok = SimpleTokenizer(REF_BPE)
+    assert len(tok.encoder) == 49408 and tok.encoder["<|startoftext|>"] == 49406 and tok.encoder["<|endoftext|>"] == 49407
+    g = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    monkeypatch.setattr(C, "_tokenizer", tok)
+    names = [str(c) for c in g["classnames"]]
+    prefix = " ".join(["X"] * 16)
+    assert np.array_equal(C.tokenize([f"a photo of a {c}." for c in names]).numpy(), g["tokens_photo"])
+    assert np.array_equal(C.tokenize([f"{prefix} {c}." for c in names], truncate=True).numpy(), g["tokens_ctx16"])
+    assert [len(tok.encode(c)) for c in names] == g["name_lens"].tolist()
+    extra = [str(s) for s in g["extra_texts"]]
+    assert np.array_equal(C.tokenize(extra, truncate=True).numpy(), g["tokens_extra"])   # html, unicode, truncation
+    with pytest.raises(RuntimeError, match="too long"):
+        C.tokenize("x " * 100)
+    assert tok.decode(tok.encode("a photo of a cat.")).strip() == "a photo of a cat ."
+
+
+def test_prompt_learner_buffers_and_identity(golden_dir):
+    from leclip_amd.clip import build_model
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import CustomCLIP, PromptLearner
+    g = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    m = build_model(synth.make_state_dict(synth.TINY, seed=1)).float()
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (32, 32)
+    pl = PromptLearner(cfg, coco_object_categories, m)
+    assert pl.n_cls == 80 and pl.n_ctx == 16 and pl.ctx.shape == (16, 128) and pl.ctx_double.shape == (16, 128)
+    assert np.array_equal(pl.tokenized_prompts.numpy(), g["tokens_ctx16"]) and pl.name_lens == g["name_lens"].tolist()
+    table = m.token_embedding.weight.detach()
+    emb = table[torch.from_numpy(g["tokens_ctx16"])]
+    assert torch.equal(pl.token_prefix, emb[:, :1]) and torch.equal(pl.token_suffix, emb[:, 17:])
+    assert torch.equal(pl.token_suffix_nocls, table[torch.from_numpy(g["tokens_ctx16_nocls"])][:, 17:])
+    assert float(pl.temperature) == 3.0 and float(pl.spatial_T) == 3.0 and float(pl.ranking_scale) == 4.0
+    assert set(pl.state_dict()) == {"ctx", "ctx_double", "ctx_evidence", "temperature", "spatial_T", "ranking_scale",
+                                    "token_prefix", "token_suffix", "token_suffix_nocls"}
+    cfg.TRAINER.Caption.CSC = True
+    assert PromptLearner(cfg, coco_object_categories, m).ctx.shape == (80, 16, 128)
+    cfg.TRAINER.Caption.CSC = False
+    cfg.TRAINER.Caption.CLASS_TOKEN_POSITION = "middle"
+    with pytest.raises(ValueError):
+        PromptLearner(cfg, coco_object_categories, m)
+    cfg.TRAINER.Caption.CLASS_TOKEN_POSITION = "end"
+    cfg.INPUT.SIZE = (224, 224)
+    with pytest.raises(AssertionError):
+        PromptLearner(cfg, coco_object_categories, m)
+    cfg.INPUT.SIZE = (32, 32)
+    cc = CustomCLIP(cfg, coco_object_categories, m)
+    trainable = [n for n, p in cc.named_parameters() if "prompt_learner" in n]
+    assert len(trainable) == 6
+
+
+def test_config_registry_and_checkpoint_layout(tmp_path):
+    from leclip_amd.registry import TRAINER_REGISTRY, build_trainer
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32"])
+    assert cfg.INPUT.SIZE == (32, 32) and cfg.TRAINER.Caption.N_CTX == 16 and cfg.TRAIN.LOSSFUNC == "double_ranking"
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.SEED = 3
+    tr = build_trainer(cfg)
+    assert "Caption_distill_double" in TRAINER_REGISTRY.registered_names() and tr.get_model_names() == ["default"]
+    model = tr.model_default
+    assert all(p.requires_grad == ("prompt_learner" in n) for n, p in model.named_parameters())
+    with torch.no_grad():
+        model.prompt_learner.ctx.fill_(0.25)
+    tr.save_model(3, str(tmp_path))
+    f = tmp_path / "default" / "model.pth.tar-3"
+    assert f.exists() and (tmp_path / "default" / "checkpoint").read_text().strip() == "model.pth.tar-3"
+    ck = torch.load(f, map_location="cpu")
+    assert set(ck) == {"state_dict", "epoch", "optimizer", "scheduler"} and ck["epoch"] == 3
+    # reference-style checkpoint: "module." prefixes and stale token buffers must be tolerated
+    sd = {"module." + k: v for k, v in ck["state_dict"].items()}
+    sd["module.token_prefix"] = torch.zeros(1)
+    torch.save({"state_dict": sd, "epoch": 7}, tmp_path / "default" / "model.pth.tar-7")
+    with torch.no_grad():
+        model.prompt_learner.ctx.zero_()
+    tr.load_model(str(tmp_path), epoch=7)
+    assert float(model.prompt_learner.ctx.mean()) == 0.25
+    with pytest.raises(FileNotFoundError):
+        tr.load_model(str(tmp_path), epoch=99)
+    with pytest.raises(NotImplementedError):
+        tr.forward_backward({})
+
+
+def test_evaluator_matches_reference_kats(golden_dir):
+    from leclip_amd.evaluation import MLClassification, average_precision, mAP
+    g = np.load(os.path.join(golden_dir, "metrics_kat.npz"))
+    for case in ("random", "ties", "allneg", "single"):
+        tt, pp = g[f"map.{case}.targets"], g[f"map.{case}.preds"]
+        assert mAP(tt, pp) == pytest.approx(float(g[f"map.{case}.value"]), abs=1e-9)
+        ap = [average_precision(pp[:, c], tt[:, c]) for c in range(pp.shape[1])]
+        np.testing.assert_allclose(ap, g[f"map.{case}.ap"], atol=1e-12)
+    ev = MLClassification(get_cfg_default())
+    tt, pp = g["map.random.targets"], g["map.random.preds"]
+    ev.process(torch.from_numpy(pp[:30]), torch.from_numpy(tt[:30]))
+    ev.process(torch.from_numpy(pp[30:]), torch.from_numpy(tt[30:]))
+    assert ev.evaluate()["mAP"] == pytest.approx(float(g["map.random.value"]), abs=1e-4)
+    assert mAP(np.zeros((0, 3)), np.zeros((0, 3))) == 0
+    from leclip_amd.trainers.utils import norm_logits_BCEloss, ranking_loss
+    yp, yt = torch.from_numpy(g["loss.pred"]), torch.from_numpy(g["loss.target"])
+    assert float(ranking_loss(yp, yt)) == pytest.approx(float(g["loss.ranking_s2"]), rel=1e-5)
+    assert float(norm_logits_BCEloss(yp, yt)) == pytest.approx(float(g["loss.bce"]), rel=1e-5)
