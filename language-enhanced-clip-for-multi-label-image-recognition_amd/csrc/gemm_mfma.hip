@@ -16,7 +16,9 @@ namespace {
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = BM * BK * 2;          // 16 KiB per operand tile
 constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
-constexpr int LDS_BYTES = 2 * STAGE_BYTES;       // double buffered: 64 KiB -> 2 workgroups per CU
+constexpr int EPI_LD = 68;                       // floats per staged epilogue row (64 + 4 pad)
+constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4;  // one wave's 64x64 fp32 tile
+constexpr int LDS_BYTES = 4 * EPI_WAVE_BYTES;    // 68 KiB >= 2 * STAGE_BYTES (64 KiB): 2 workgroups per CU
 
 struct GemmArgs {
     const void* A;
@@ -111,22 +113,80 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
         __syncthreads();
     }
 
-    // epilogue: accumulator (i,j) register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31
+    // ---- epilogue.  Accumulator (i,j) register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31: a
+    // row-major store straight from registers would be 2-byte scalars in 64-byte runs.  Instead each wave parks its
+    // 64x64 fp32 tile in its own LDS region (the K-loop buffers are dead after the final barrier; rows padded to 68
+    // floats so the column-per-lane ds_write_b32 are conflict-free), then re-reads it row-major, 8 columns per lane:
+    // bias / QuickGELU / residual are applied on 8-wide chunks, residual and output move as 16-byte accesses, and
+    // every wave-instruction covers 8 full 128-byte output lines.  Wave-local: no workgroup barrier.
     const EpiParams& e = g.epi;
+    float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int64_t m = m0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-            if (m < g.M) {
-                const int64_t orow = epi_out_row(e, m);
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int n = n0 + wc * 64 + j * 32 + fr;
-                    const float v = epi_apply<false>(e, m, n, acc[i][j][r]);
-                    store_elem(e.out, e.out_dt, orow * e.ldy + n, v);
-                }
+            for (int r = 0; r < 16; ++r)
+                st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + j * 32 + fr] = acc[i][j][r];
+
+    const int crow = lane >> 3, ccol = (lane & 7) * 8;
+    const int n = n0 + wc * 64 + ccol;
+    float b8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b8[c] = 0.f;
+    if (e.bias) {
+        const f32x4 t0 = *(const f32x4*)(e.bias + n), t1 = *(const f32x4*)(e.bias + n + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int row = it * 8 + crow;
+        const int64_t m = m0 + wr * 64 + row;
+        const f32x4 v0 = *(const f32x4*)(st + row * EPI_LD + ccol), v1 = *(const f32x4*)(st + row * EPI_LD + ccol + 4);
+        if (m >= g.M) continue;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + b8[c]; v[4 + c] = v1[c] + b8[4 + c]; }
+        if (e.act == LECLIP_ACT_QUICKGELU) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));   // x * sigmoid(1.702 x)
+        }
+        int64_t orow = m, rrow = m;
+        if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+        if (e.res) {
+            if (e.res_dt == LECLIP_F32) {
+                const float* rp = (const float*)e.res + rrow * e.ldr + n;
+                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
+            } else if (e.res_dt == LECLIP_BF16) {
+                const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+            } else {
+                const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
             }
+        }
+        if (e.out_dt == LECLIP_F32) {
+            float* op = (float*)e.out + orow * e.ldy + n;
+            f32x4 o0, o1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { o0[c] = v[c]; o1[c] = v[4 + c]; }
+            *(f32x4*)op = o0;
+            *(f32x4*)(op + 4) = o1;
+        } else if (e.out_dt == LECLIP_BF16) {
+            bf16x8 o8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
+            *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
+        } else {
+            f16x8 o8;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
+            *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
         }
     }
 }
@@ -157,6 +217,14 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
     if ((lda % 8) || (ldw % 8) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         leclip_set_error("gemm: A/W must be 16-byte aligned with leading dimensions that are multiples of 8 elements");
         return LECLIP_E_INVALID;
+    }
+    {
+        const int oa = epi.out_dt == LECLIP_F32 ? 4 : 8, ra = epi.res_dt == LECLIP_F32 ? 4 : 8;
+        if ((epi.ldy % oa) || ((uintptr_t)epi.out & 15) || (epi.res && ((epi.ldr % ra) || ((uintptr_t)epi.res & 15))) ||
+            (epi.bias && ((uintptr_t)epi.bias & 15))) {
+            leclip_set_error("gemm: Y / residual / bias must be 16-byte aligned with 16-byte-multiple leading dimensions");
+            return LECLIP_E_INVALID;
+        }
     }
     GemmArgs a;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;

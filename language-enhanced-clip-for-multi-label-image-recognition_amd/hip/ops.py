@@ -15,6 +15,36 @@ from ._capi import ACT_NONE, ACT_QUICKGELU, MASK_CAUSAL, MASK_NONE
 _DT = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.bfloat16: _capi.BF16}
 
 
+# Optional per-launch timing hook (bench.py): when a list is installed, gemm()/attention()/layernorm() bracket
+# their launch with HIP events on the launch stream and append (kernel family, algorithmic flops, bytes, e0, e1).
+_PROFILE = None
+
+
+def set_profile(sink):
+    global _PROFILE
+    _PROFILE = sink
+
+
+class _Timed:
+    __slots__ = ("name", "flops", "nbytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROFILE.append((self.name, self.flops, self.nbytes, self.e0, e1))
+        return False
+
+
 def dtype_code(dt: torch.dtype) -> int:
     try:
         return _DT[dt]
@@ -58,9 +88,10 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
         out = torch.empty(x.shape, dtype=out_dtype or x.dtype, device=x.device)
     _, _, ldy = _rows2d(out, "out")
     assert gamma.dtype == torch.float32 and beta.dtype == torch.float32 and gamma.numel() == dim == beta.numel()
-    _capi.check(_capi.load().leclip_layernorm_fwd(_ptr(x), _ptr(_dev(gamma, "gamma")), _ptr(_dev(beta, "beta")), _ptr(out),
-                                                  rows, dim, ldx, ldy, eps, dtype_code(x.dtype), dtype_code(out.dtype),
-                                                  _stream()), "layernorm")
+    with _Timed("layernorm", 0, rows * dim * (x.element_size() + out.element_size())):
+        _capi.check(_capi.load().leclip_layernorm_fwd(_ptr(x), _ptr(_dev(gamma, "gamma")), _ptr(_dev(beta, "beta")), _ptr(out),
+                                                      rows, dim, ldx, ldy, eps, dtype_code(x.dtype), dtype_code(out.dtype),
+                                                      _stream()), "layernorm")
     return out
 
 
@@ -84,9 +115,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if bias is not None:
         assert bias.dtype == torch.float32 and bias.numel() == n
         _dev(bias, "bias")
-    _capi.check(_capi.load().leclip_gemm_bias_act_res_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), m, n, k,
-                                                          lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
-                                                          dtype_code(out.dtype), _stream()), "gemm")
+    nbytes = (m * k + n * k) * a.element_size() + m * n * out.element_size() + (m * n * residual.element_size() if residual is not None else 0)
+    with _Timed("gemm", 2 * m * n * k, nbytes):
+        _capi.check(_capi.load().leclip_gemm_bias_act_res_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), m, n, k,
+                                                              lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
+                                                              dtype_code(out.dtype), _stream()), "gemm")
     return out
 
 
@@ -110,9 +143,12 @@ def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, 
         workspace = patch_embed_workspace(b, r, patch, wp.dtype, image.device)
     if out is None:
         out = torch.empty((b, t, width), dtype=x_dtype, device=image.device)
-    _capi.check(_capi.load().leclip_patch_embed_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(out), b, r,
-                                                    patch, width, dtype_code(image.dtype), dtype_code(wp.dtype),
-                                                    dtype_code(out.dtype), _ptr(workspace), _stream()), "patch_embed")
+    npatch = b * (t - 1)
+    with _Timed("patch_embed", 2 * npatch * width * 3 * patch * patch,
+                image.numel() * image.element_size() + npatch * wp.shape[1] * wp.element_size() * 2 + b * t * width * out.element_size()):
+        _capi.check(_capi.load().leclip_patch_embed_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(out), b, r,
+                                                        patch, width, dtype_code(image.dtype), dtype_code(wp.dtype),
+                                                        dtype_code(out.dtype), _ptr(workspace), _stream()), "patch_embed")
     return out
 
 
@@ -125,9 +161,10 @@ def attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, causal: bo
     if out is None:
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
     _, _, ldo = _rows2d(out, "out")
-    _capi.check(_capi.load().leclip_attention_fwd(_ptr(qkv), _ptr(out), batch, tokens, heads, 64, ld, ldo,
-                                                  MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype),
-                                                  _stream()), "attention")
+    with _Timed("attention", 4 * batch * heads * tokens * tokens * 64, rows * 4 * d * qkv.element_size()):
+        _capi.check(_capi.load().leclip_attention_fwd(_ptr(qkv), _ptr(out), batch, tokens, heads, 64, ld, ldo,
+                                                      MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype),
+                                                      _stream()), "attention")
     return out
 
 
