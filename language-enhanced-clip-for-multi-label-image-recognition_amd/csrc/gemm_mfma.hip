@@ -206,6 +206,9 @@ int launch_mfma(const GemmArgs& a, hipStream_t s) {
 
 int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                            const EpiParams& epi, hipStream_t s);
+bool leclip_gemm256_eligible(int64_t M, int N, int K);
+int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                          const EpiParams& epi, int ab_dtype, hipStream_t s);
 
 int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                          const EpiParams& epi, int ab_dtype, hipStream_t s) {
@@ -226,6 +229,7 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
             return LECLIP_E_INVALID;
         }
     }
+    if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     GemmArgs a;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;
     const int64_t tiles_m = (M + BM - 1) / BM;
@@ -238,7 +242,8 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
 extern "C" const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_dtype ab_dtype) {
     (void)M;
     if (ab_dtype == LECLIP_F32) return (N % 64 == 0 && K % 32 == 0) ? "gemm_f32_64x64x32" : "unsupported";
-    return (N % BN == 0 && K % BK == 0) ? "gemm_tn_128x128x64" : "unsupported";
+    if (N % BN != 0 || K % BK != 0) return "unsupported";
+    return leclip_gemm256_eligible(M, N, K) ? "gemm_tn_256x256x64_pp" : "gemm_tn_128x128x64";
 }
 
 extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias, const void* residual,

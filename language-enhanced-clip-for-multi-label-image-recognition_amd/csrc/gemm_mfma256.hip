@@ -1,0 +1,323 @@
+// Y = act(A . W^T + bias) + residual, large-M throughput kernel: 256x256 output tile, 8 waves, ping-pong schedule.
+//
+// "gemm_tn_256x256x64_pp".  One 512-thread workgroup per CU owns a 256x256 tile; waves are 2 (M) x 4 (N), each
+// holding a 128x64 fp32 accumulator block (128 VGPRs) fed by v_mfma_f32_16x16x32 (bf16 / fp16).  The two waves that
+// share a SIMD (wave w and w+4 = the two M-halves) run the same program one barrier apart: while one executes a
+// 16-MFMA compute cluster the other executes its memory cluster (LDS fragment reads + LDS-DMA issue), so the matrix
+// pipe of every SIMD is fed continuously without either wave interleaving loads and MFMAs itself.
+//
+// K-loop, BK = 64 per K-tile, two K-tile stages resident in LDS (128 KiB).  Each stage is FOUR 16 KiB slots split
+// along K, not along rows:  A[256 rows][k 0..31], B[256][k 0..31], A[256][k 32..63], B[256][k 32..63]  (64-byte rows).
+// A K-tile is consumed in four phases, each 16 MFMAs on one (row-half, k-half):
+//     phase 0: read A(k0, rows r0) + B(k0)   phase 1: read A(k0, r1)   phase 2: read A(k1, r0) + B(k1)   phase 3: read A(k1, r1)
+// so a slot is dead early (B(k0) after phase 0, A(k0) after 1, B(k1) after 2, A(k1) after 3) and is refilled - two
+// phases after its last read, for the K-tile two ahead - while the rest of the current tile is still being
+// consumed.  Every LDS-DMA (global_load_lds_dwordx4, 2 per wave per slot) therefore has 5-6 phases (>2500 cycles) to
+// land; waits are counted (s_waitcnt vmcnt(8)), never vmcnt(0) in the steady state, barriers are raw s_barrier.
+//     tile t, stage s=t&1:  phase 0 stages B(1-s,k1)(t+1)   phase 1 stages A(1-s,k1)(t+1) ; vmcnt -> k1 slots of tile t landed
+//                           phase 2 stages B(s,k0)(t+2)     phase 3 stages A(s,k0)(t+2)   ; vmcnt -> k0 slots of tile t+1 landed
+// RAW: a slot is read one phase after the counted wait that retires it (the wait precedes that phase's first barrier;
+// with the one-barrier stagger both wave groups have passed their wait before either reads).  WAR: restaged >= 2
+// phases after its last ds_read (those reads were retired by lgkmcnt(0) in the reader's compute cluster, which ends
+// one full barrier interval before the restage for either group).
+// LDS bank swizzle (64-byte rows, 4 rows per 256-byte bank row): 16-byte chunk c of row r is stored at chunk
+// c ^ f((r>>2)&3), f = {0,3,2,1}: every ds_read_b128 16-lane group then touches 16 distinct 16-byte slots.  The image
+// is lane-linear per LDS-DMA instruction, so the XOR is applied to the per-lane SOURCE address and to the read address.
+#include "leclip_common.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int SLOT_BYTES = 256 * 64;            // 256 rows x 32 k x 2 B
+constexpr int STAGE_BYTES = 4 * SLOT_BYTES;     // A.k0 | B.k0 | A.k1 | B.k1
+constexpr int EPI_LD = 68;
+constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4; // 64x64 fp32 per wave per pass
+constexpr int LDS_BYTES = 8 * EPI_WAVE_BYTES;   // 136 KiB >= 2 * STAGE_BYTES (128 KiB)
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+
+__device__ __forceinline__ acc4 mfma16(bf16x8 a, bf16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ acc4 mfma16(f16x8 a, f16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+struct Gemm256Args {
+    const void* A;
+    const void* W;
+    int64_t M;
+    int N, K;
+    int64_t lda, ldw;
+    EpiParams epi;
+    int tiles_n, tiles_total;
+};
+
+__device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+
+template <typename T>
+struct PP {
+    typedef typename VecOf<T>::v8 v8;
+    // per-lane constants
+    const T* a_src[2];   // global source of this lane's two LDS-DMA pieces of an A slot (k offset added per use)
+    const T* w_src[2];
+    int dma_off[2];      // wave-uniform LDS byte offset of the two pieces inside a slot
+    int a_rd;            // LDS byte offset (inside an A slot) of this lane's fragment row/chunk, row-half 0, tile 0
+    int b_rd;            // same for a B slot
+    char* smem;
+    acc4 acc[2][4][4];
+    v8 af[4], bfr[4];
+
+    __device__ __forceinline__ void stage_a(int stage, int kh, int k_elem) {
+        char* slot = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((const void*)(a_src[u] + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
+    }
+    __device__ __forceinline__ void stage_b(int stage, int kh, int k_elem) {
+        char* slot = smem + stage * STAGE_BYTES + (2 * kh + 1) * SLOT_BYTES;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            __builtin_amdgcn_global_load_lds((const void*)(w_src[u] + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
+    }
+    __device__ __forceinline__ void read_a(int stage, int kh, int rh) {
+        const char* p = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES + a_rd + rh * (64 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = *(const v8*)(p + i * 1024);
+    }
+    __device__ __forceinline__ void read_b(int stage, int kh) {
+        const char* p = smem + stage * STAGE_BYTES + (2 * kh + 1) * SLOT_BYTES + b_rd;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = *(const v8*)(p + j * 1024);
+    }
+    __device__ __forceinline__ void compute(int rh) {
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PIN();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[rh][i][j] = mfma16(af[i], bfr[j], acc[rh][i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        PIN();
+        __builtin_amdgcn_s_barrier();
+        PIN();
+    }
+
+    // One K-tile.  V = 0 steady state (tiles t+1 and t+2 exist), 1 = second to last (only t+1 exists), 2 = last.
+    template <int V>
+    __device__ __forceinline__ void ktile(int t) {
+        const int s = t & 1;
+        const int k1 = (t + 1) * TK, k2 = (t + 2) * TK;
+        // ---- phase 0: (k0, r0)
+        read_a(s, 0, 0);
+        read_b(s, 0);
+        if (V <= 1) stage_b(1 - s, 1, k1 + 32);
+        PIN();
+        compute(0);
+        // ---- phase 1: (k0, r1)
+        read_a(s, 0, 1);
+        if (V <= 1) stage_a(1 - s, 1, k1 + 32);
+        if (V <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // k1 slots of tile t landed (this wave's pieces)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        PIN();
+        compute(1);
+        // ---- phase 2: (k1, r0)
+        read_a(s, 1, 0);
+        read_b(s, 1);
+        if (V == 0) stage_b(s, 0, k2);
+        PIN();
+        compute(0);
+        // ---- phase 3: (k1, r1)
+        read_a(s, 1, 1);
+        if (V == 0) stage_a(s, 0, k2);
+        if (V == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // k0 slots of tile t+1 landed
+        else if (V == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        PIN();
+        compute(1);
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int tile = xcd_remap256(blockIdx.x, g.tiles_total);
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+    const int64_t m0 = (int64_t)tm * TM;
+    const int n0 = tn * TN;
+
+    PP<T> p;
+    p.smem = smem;
+    {
+        // LDS-DMA pieces: a slot is 16 pieces of 16 rows x 64 B; wave w issues pieces w and w+8.  Lane l writes
+        // row 16*piece + (l>>2), physical chunk l&3, which must hold logical chunk (l&3) ^ f((row>>2)&3).
+        const int fsw = (4 - ((lane >> 4) & 3)) & 3;   // (row>>2)&3 == (lane>>4)&3 inside a piece
+        const int c = (lane & 3) ^ fsw;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int piece = wave + 8 * u;
+            const int r = piece * 16 + (lane >> 2);
+            int64_t ar = m0 + r;
+            ar = ar < g.M ? ar : g.M - 1;
+            p.a_src[u] = (const T*)g.A + ar * g.lda + c * 8;
+            p.w_src[u] = (const T*)g.W + (int64_t)(n0 + r) * g.ldw + c * 8;
+            p.dma_off[u] = piece * 1024;
+        }
+        // fragment reads (v_mfma_f32_16x16x32 operand map): lane l -> row l&15 of a 16-row tile, 16-byte chunk l>>4
+        const int fr = lane & 15, fc = lane >> 4;
+        const int frd = fr * 64 + ((fc ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4);
+        p.a_rd = wm * (128 * 64) + frd;
+        p.b_rd = wn * (64 * 64) + frd;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p.acc[h][i][j][r] = 0.f;
+
+    const int nk = g.K / TK;   // >= 2 (checked by the host)
+    // ---- prologue: tile 0 completely, tile 1's k0 slots; 12 LDS-DMA per wave, wait for the first 4 (tile 0, k0)
+    p.stage_b(0, 0, 0);
+    p.stage_a(0, 0, 0);
+    p.stage_b(0, 1, 32);
+    p.stage_a(0, 1, 32);
+    p.stage_b(1, 0, TK);
+    p.stage_a(1, 0, TK);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    PIN();
+    __builtin_amdgcn_s_barrier();
+    PIN();
+    if (wm == 1) __builtin_amdgcn_s_barrier();   // stagger: the second M-half runs one barrier behind
+    PIN();
+
+    int t = 0;
+    for (; t + 2 < nk; ++t) p.template ktile<0>(t);
+    p.template ktile<1>(t);
+    p.template ktile<2>(t + 1);
+
+    if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
+    PIN();
+    __syncthreads();                             // every wave is done reading the K-loop buffers
+
+    // ---- epilogue: per wave, two passes (row halves) of a 64x64 fp32 tile parked in the wave's own LDS region and
+    // re-read row-major, 8 columns per lane -> bias / QuickGELU / residual on 8-wide chunks, 16-byte stores.
+    const EpiParams& e = g.epi;
+    float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
+    const int crow = lane >> 3, ccol = (lane & 7) * 8;
+    const int n = n0 + wn * 64 + ccol;
+    float b8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) b8[c] = 0.f;
+    if (e.bias) {
+        const f32x4 t0 = *(const f32x4*)(e.bias + n), t1 = *(const f32x4*)(e.bias + n + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        // accumulator (i,j) register r: row 16i + 4*(lane>>4) + r, column 16j + (lane&15)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    st[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = p.acc[h][i][j][r];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = it * 8 + crow;
+            const int64_t m = m0 + wm * 128 + h * 64 + row;
+            const f32x4 v0 = *(const f32x4*)(st + row * EPI_LD + ccol), v1 = *(const f32x4*)(st + row * EPI_LD + ccol + 4);
+            if (m >= g.M) continue;
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] = v0[c] + b8[c]; v[4 + c] = v1[c] + b8[4 + c]; }
+            if (e.act == LECLIP_ACT_QUICKGELU) {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));
+            }
+            int64_t orow = m, rrow = m;
+            if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+            if (e.res) {
+                if (e.res_dt == LECLIP_F32) {
+                    const float* rp = (const float*)e.res + rrow * e.ldr + n;
+                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
+                } else if (e.res_dt == LECLIP_BF16) {
+                    const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+                } else {
+                    const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+                }
+            }
+            if (e.out_dt == LECLIP_F32) {
+                float* op = (float*)e.out + orow * e.ldy + n;
+                f32x4 o0, o1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { o0[c] = v[c]; o1[c] = v[4 + c]; }
+                *(f32x4*)op = o0;
+                *(f32x4*)(op + 4) = o1;
+            } else if (e.out_dt == LECLIP_BF16) {
+                bf16x8 o8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
+                *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
+            } else {
+                f16x8 o8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
+                *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
+            }
+        }
+    }
+}
+
+template <typename T>
+int launch256(const Gemm256Args& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_tn_256x256x64_pp<T>, dim3(a.tiles_total), dim3(512), LDS_BYTES, s, a);
+    return leclip_check_launch("gemm_tn_256x256x64_pp");
+}
+
+}  // namespace
+
+// Shapes this kernel takes: N % 256 == 0, K % 64 == 0, K >= 128; worth it only when the grid fills the chip.
+bool leclip_gemm256_eligible(int64_t M, int N, int K) {
+    if (N % TN != 0 || K % TK != 0 || K < 2 * TK) return false;
+    // LECLIP_GEMM_TILE=256 / 128 forces a kernel family (tests, A/B timing); unset = heuristic below
+    static const int forced = [] { const char* e = getenv("LECLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
+    if (forced == 256) return true;
+    if (forced == 128) return false;
+    const int64_t tiles = ((M + TM - 1) / TM) * (N / TN);
+    return tiles >= 192;
+}
+
+int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                          const EpiParams& epi, int ab_dtype, hipStream_t s) {
+    Gemm256Args a;
+    a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;
+    const int64_t tiles_m = (M + TM - 1) / TM;
+    a.tiles_n = N / TN;
+    if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
+    a.tiles_total = (int)(tiles_m * a.tiles_n);
+    return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
+}

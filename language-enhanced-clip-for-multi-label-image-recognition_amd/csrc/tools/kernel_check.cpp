@@ -184,6 +184,13 @@ int main(int argc, char** argv) {
         check_gemm(333, 384, 192, dt, LECLIP_F32, dt, 1, true, false);
         check_gemm(1576, 256, 3072, dt, LECLIP_F32, LECLIP_F32, 1, true, true);
     }
+    // shapes that qualify for the 256x256 ping-pong kernel when LECLIP_GEMM_TILE=256 (K-tiles: 2, 3, 12; ragged M)
+    for (int dt : {LECLIP_BF16, LECLIP_F16}) {
+        check_gemm(700, 512, 128, dt, LECLIP_F32, LECLIP_F32, 0, false, false);
+        check_gemm(1000, 256, 192, dt, dt, dt, 1, true, true);
+        check_gemm(513, 768, 768, dt, dt, dt, 0, true, true);
+        check_gemm(256, 256, 256, dt, LECLIP_F32, LECLIP_F32, 0, true, false);
+    }
     check_gemm(200, 64, 32, LECLIP_F32, LECLIP_F32, LECLIP_F32, 0, false, false);
     check_gemm(777, 192, 160, LECLIP_F32, LECLIP_F32, LECLIP_F32, 1, true, true);
     for (int dt : {LECLIP_BF16, LECLIP_F16, LECLIP_F32}) {
