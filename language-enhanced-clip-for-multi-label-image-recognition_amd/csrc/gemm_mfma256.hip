@@ -31,9 +31,8 @@ namespace {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int SLOT_BYTES = 256 * 64;            // 256 rows x 32 k x 2 B
 constexpr int STAGE_BYTES = 4 * SLOT_BYTES;     // A.k0 | B.k0 | A.k1 | B.k1
-constexpr int EPI_LD = 68;
-constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4; // 64x64 fp32 per wave per pass
-constexpr int LDS_BYTES = 8 * EPI_WAVE_BYTES;   // 136 KiB >= 2 * STAGE_BYTES (128 KiB)
+constexpr int EPI_WAVE_BYTES = 16 * 64 * 4;     // 16x64 fp32 strip per wave per epilogue pass
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + 8 * EPI_WAVE_BYTES;   // 128 KiB K-loop stages + 32 KiB epilogue staging = 160 KiB
 
 typedef __attribute__((ext_vector_type(4))) float acc4;
 
@@ -48,6 +47,8 @@ struct Gemm256Args {
     int64_t lda, ldw;
     EpiParams epi;
     int tiles_n, tiles_total;
+    int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
+    int dbg;   // diagnostic: 1 skip epilogue, 2 skip global stores, 4 skip K-loop (LECLIP_GEMM_DEBUG; timing experiments only)
 };
 
 __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
@@ -149,141 +150,181 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    const int tile = xcd_remap256(blockIdx.x, g.tiles_total);
-    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
-    const int64_t m0 = (int64_t)tm * TM;
-    const int n0 = tn * TN;
-
     PP<T> p;
     p.smem = smem;
+    // fragment reads (v_mfma_f32_16x16x32 operand map): lane l -> row l&15 of a 16-row tile, 16-byte chunk l>>4
     {
-        // LDS-DMA pieces: a slot is 16 pieces of 16 rows x 64 B; wave w issues pieces w and w+8.  Lane l writes
-        // row 16*piece + (l>>2), physical chunk l&3, which must hold logical chunk (l&3) ^ f((row>>2)&3).
-        const int fsw = (4 - ((lane >> 4) & 3)) & 3;   // (row>>2)&3 == (lane>>4)&3 inside a piece
-        const int c = (lane & 3) ^ fsw;
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int piece = wave + 8 * u;
-            const int r = piece * 16 + (lane >> 2);
-            int64_t ar = m0 + r;
-            ar = ar < g.M ? ar : g.M - 1;
-            p.a_src[u] = (const T*)g.A + ar * g.lda + c * 8;
-            p.w_src[u] = (const T*)g.W + (int64_t)(n0 + r) * g.ldw + c * 8;
-            p.dma_off[u] = piece * 1024;
-        }
-        // fragment reads (v_mfma_f32_16x16x32 operand map): lane l -> row l&15 of a 16-row tile, 16-byte chunk l>>4
         const int fr = lane & 15, fc = lane >> 4;
         const int frd = fr * 64 + ((fc ^ ((4 - ((fr >> 2) & 3)) & 3)) << 4);
         p.a_rd = wm * (128 * 64) + frd;
         p.b_rd = wn * (64 * 64) + frd;
+        p.dma_off[0] = wave * 1024;
+        p.dma_off[1] = (wave + 8) * 1024;
     }
-#pragma unroll
-    for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) p.acc[h][i][j][r] = 0.f;
-
+    // LDS-DMA pieces: a slot is 16 pieces of 16 rows x 64 B; wave w issues pieces w and w+8.  Lane l writes row
+    // 16*piece + (l>>2), physical chunk l&3, which must hold logical chunk (l&3) ^ f((row>>2)&3), (row>>2)&3 == (l>>4)&3.
+    const int dma_c = ((lane & 3) ^ ((4 - ((lane >> 4) & 3)) & 3)) * 8;
+    const int dma_r = lane >> 2;
     const int nk = g.K / TK;   // >= 2 (checked by the host)
-    // ---- prologue: tile 0 completely, tile 1's k0 slots; 12 LDS-DMA per wave, wait for the first 4 (tile 0, k0)
-    p.stage_b(0, 0, 0);
-    p.stage_a(0, 0, 0);
-    p.stage_b(0, 1, 32);
-    p.stage_a(0, 1, 32);
-    p.stage_b(1, 0, TK);
-    p.stage_a(1, 0, TK);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    PIN();
-    __builtin_amdgcn_s_barrier();
-    PIN();
-    if (wm == 1) __builtin_amdgcn_s_barrier();   // stagger: the second M-half runs one barrier behind
-    PIN();
-
-    int t = 0;
-    for (; t + 2 < nk; ++t) p.template ktile<0>(t);
-    p.template ktile<1>(t);
-    p.template ktile<2>(t + 1);
-
-    if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
-    PIN();
-    __syncthreads();                             // every wave is done reading the K-loop buffers
-
-    // ---- epilogue: per wave, two passes (row halves) of a 64x64 fp32 tile parked in the wave's own LDS region and
-    // re-read row-major, 8 columns per lane -> bias / QuickGELU / residual on 8-wide chunks, 16-byte stores.
     const EpiParams& e = g.epi;
-    float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
-    const int crow = lane >> 3, ccol = (lane & 7) * 8;
-    const int n = n0 + wn * 64 + ccol;
-    float b8[8];
+
+    auto tile_origin = [&](int v, int64_t& m0, int& n0) {
+        const int tile = xcd_remap256(v, g.tiles_total);
+        const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+        m0 = (int64_t)tm * TM;
+        n0 = tn * TN;
+    };
+    // first K-tiles of a tile: tile 0 completely, tile 1's k0 slots; 12 LDS-DMA per wave
+    auto prologue = [&](int64_t m0, int n0) {
 #pragma unroll
-    for (int c = 0; c < 8; ++c) b8[c] = 0.f;
-    if (e.bias) {
-        const f32x4 t0 = *(const f32x4*)(e.bias + n), t1 = *(const f32x4*)(e.bias + n + 4);
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
+        for (int u = 0; u < 2; ++u) {
+            const int r = (wave + 8 * u) * 16 + dma_r;
+            int64_t ar = m0 + r;
+            ar = ar < g.M ? ar : g.M - 1;
+            p.a_src[u] = (const T*)g.A + ar * g.lda + dma_c;
+            p.w_src[u] = (const T*)g.W + (int64_t)(n0 + r) * g.ldw + dma_c;
+        }
+        p.stage_b(0, 0, 0);
+        p.stage_a(0, 0, 0);
+        p.stage_b(0, 1, 32);
+        p.stage_a(0, 1, 32);
+        p.stage_b(1, 0, TK);
+        p.stage_a(1, 0, TK);
+    };
+
+    // Persistent over tiles: workgroup b takes virtual block ids b, b + grid, ...  The next tile's prologue DMA is
+    // issued before this tile's epilogue (the K-loop buffers are dead by then, the epilogue stages through its own
+    // 32 KiB), so its HBM/L2 latency and the epilogue's stores overlap.
+    // De-synchronise the CUs: all workgroups start together and would otherwise run K-loops and epilogues in
+    // lockstep, leaving HBM idle during the K-loops and saturated (MFMA idle) during the store bursts.
+    if (g.desync) {
+        const int phi = (blockIdx.x >> 3) & 3;
+        for (int i = 0; i < phi * g.desync; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    int v = blockIdx.x;
+    int64_t m0;
+    int n0;
+    tile_origin(v, m0, n0);
+    prologue(m0, n0);
+    while (true) {
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        // accumulator (i,j) register r: row 16i + 4*(lane>>4) + r, column 16j + (lane&15)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    st[(i * 16 + 4 * (lane >> 4) + r) * EPI_LD + j * 16 + (lane & 15)] = p.acc[h][i][j][r];
+                    for (int r = 0; r < 4; ++r) p.acc[h][i][j][r] = 0.f;
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0, k0 slots (at least) have landed
+        PIN();
+        __builtin_amdgcn_s_barrier();
+        PIN();
+        if (wm == 1) __builtin_amdgcn_s_barrier();   // stagger: the second M-half runs one barrier behind
+        PIN();
+
+        int t = 0;
+        if (g.dbg & 4) t = nk - 2 > 0 ? nk - 2 : 0;
+        for (; t + 2 < nk; ++t) p.template ktile<0>(t);
+        p.template ktile<1>(t);
+        p.template ktile<2>(t + 1);
+
+        if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
+        PIN();
+        __syncthreads();                             // every wave is done reading the K-loop buffers
+
+        const int64_t em0 = m0;
+        const int en0 = n0;
+        const int vn = v + gridDim.x;
+        const bool more = vn < g.tiles_total;
+        float b8[8];
+        const int crow = lane >> 3, ccol = (lane & 7) * 8;
+        const int n = en0 + wn * 64 + ccol;
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int row = it * 8 + crow;
-            const int64_t m = m0 + wm * 128 + h * 64 + row;
-            const f32x4 v0 = *(const f32x4*)(st + row * EPI_LD + ccol), v1 = *(const f32x4*)(st + row * EPI_LD + ccol + 4);
-            if (m >= g.M) continue;
-            float v[8];
+        for (int c = 0; c < 8; ++c) b8[c] = 0.f;
+        if (e.bias) {
+            const f32x4 t0 = *(const f32x4*)(e.bias + n), t1 = *(const f32x4*)(e.bias + n + 4);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { v[c] = v0[c] + b8[c]; v[4 + c] = v1[c] + b8[4 + c]; }
-            if (e.act == LECLIP_ACT_QUICKGELU) {
+            for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
+        }
+        if (more) {
+            tile_origin(vn, m0, n0);
+            prologue(m0, n0);
+        }
+
+        // ---- epilogue: 8 passes of 16 rows.  The wave parks a 16x64 fp32 strip in its own 4 KiB staging region
+        // (column block XOR-swizzled by (row>>2)&1 so the column-per-lane ds_write_b32 do not conflict) and re-reads
+        // it row-major, 8 columns per lane: bias / QuickGELU / residual on 8-wide chunks, 16-byte global accesses.
+        if (!(g.dbg & 1)) {
+            float* st = (float*)(smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
+            const int wsw = ((lane >> 4) & 1) << 4;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));
-            }
-            int64_t orow = m, rrow = m;
-            if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
-            if (e.res) {
-                if (e.res_dt == LECLIP_F32) {
-                    const float* rp = (const float*)e.res + rrow * e.ldr + n;
-                    const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+            for (int q = 0; q < 8; ++q) {
+                const int h = q >> 2, i = q & 3;
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
-                } else if (e.res_dt == LECLIP_BF16) {
-                    const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
-                } else {
-                    const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+                    for (int r = 0; r < 4; ++r)
+                        st[(4 * (lane >> 4) + r) * 64 + ((16 * j) ^ wsw) + (lane & 15)] = p.acc[h][i][j][r];
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+                for (int u = 0; u < 2; ++u) {
+                    const int row = u * 8 + crow;
+                    const int64_t m = em0 + wm * 128 + h * 64 + i * 16 + row;
+                    const float* sp = st + row * 64 + (ccol ^ (((row >> 2) & 1) << 4));
+                    const f32x4 v0 = *(const f32x4*)sp, v1 = *(const f32x4*)(sp + 4);
+                    if (m >= g.M) continue;
+                    float vv[8];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { vv[c] = v0[c] + b8[c]; vv[4 + c] = v1[c] + b8[4 + c]; }
+                    if (e.act == LECLIP_ACT_QUICKGELU) {
+                        // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): v_exp_f32 + v_rcp_f32
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            vv[c] = vv[c] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * vv[c]));
+                    }
+                    if ((g.dbg & 2) && vv[0] != 12345.678f) continue;
+                    int64_t orow = m, rrow = m;
+                    if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+                    if (e.res) {
+                        if (e.res_dt == LECLIP_F32) {
+                            const float* rp = (const float*)e.res + rrow * e.ldr + n;
+                            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+                            for (int c = 0; c < 4; ++c) { vv[c] += r0[c]; vv[4 + c] += r1[c]; }
+                        } else if (e.res_dt == LECLIP_BF16) {
+                            const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
+                        } else {
+                            const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
+                        }
+                    }
+                    if (e.out_dt == LECLIP_F32) {
+                        float* op = (float*)e.out + orow * e.ldy + n;
+                        f32x4 o0, o1;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) { o0[c] = vv[c]; o1[c] = vv[4 + c]; }
+                        *(f32x4*)op = o0;
+                        *(f32x4*)(op + 4) = o1;
+                    } else if (e.out_dt == LECLIP_BF16) {
+                        bf16x8 o8;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)vv[c];
+                        *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
+                    } else {
+                        f16x8 o8;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) o8[c] = (f16_t)vv[c];
+                        *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
+                    }
                 }
             }
-            if (e.out_dt == LECLIP_F32) {
-                float* op = (float*)e.out + orow * e.ldy + n;
-                f32x4 o0, o1;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { o0[c] = v[c]; o1[c] = v[4 + c]; }
-                *(f32x4*)op = o0;
-                *(f32x4*)(op + 4) = o1;
-            } else if (e.out_dt == LECLIP_BF16) {
-                bf16x8 o8;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
-                *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
-            } else {
-                f16x8 o8;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
-                *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
-            }
+        } else if (p.acc[0][0][0][0] == 12345.678f) {
+            ((float*)e.out)[0] = 1.f;
         }
+        if (!more) break;
+        v = vn;
     }
 }
 
@@ -294,7 +335,16 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(gemm_tn_256x256x64_pp<T>, dim3(a.tiles_total), dim3(512), LDS_BYTES, s, a);
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    static const int cap = [] { const char* e = getenv("LECLIP_GEMM_GRID"); return e ? atoi(e) : 0; }();   // test hook: force multi-tile loops
+    const int limit = cap > 0 ? cap : n_cu;
+    const int grid = a.tiles_total < limit ? a.tiles_total : limit;   // one persistent workgroup per CU (160 KiB LDS each)
+    hipLaunchKernelGGL(gemm_tn_256x256x64_pp<T>, dim3(grid), dim3(512), LDS_BYTES, s, a);
     return leclip_check_launch("gemm_tn_256x256x64_pp");
 }
 
@@ -319,5 +369,9 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.tiles_n = N / TN;
     if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
     a.tiles_total = (int)(tiles_m * a.tiles_n);
+    static const int dbg = [] { const char* e = getenv("LECLIP_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
+    a.dbg = dbg;
+    static const int desync = [] { const char* e = getenv("LECLIP_GEMM_DESYNC"); return e ? atoi(e) : 0; }();
+    a.desync = desync;
     return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
 }

@@ -146,7 +146,9 @@ static void bench() {
     const int64_t M = 256 * 197;
     struct S { int N, K, act; bool res; const char* name; } shapes[] = {
         {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
+    const bool quick = getenv("LECLIP_BENCH_QUICK") != nullptr;
     for (int dt : {LECLIP_BF16, LECLIP_F16}) for (auto& s : shapes) {
+        if (quick && dt != LECLIP_BF16) continue;
         auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
         auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
         Buf dA(Ap.size()), dW(Wp.size()), dB(s.N * 4), dR(Rp.size()), dY((size_t)M * s.N * 2);
@@ -157,7 +159,7 @@ static void bench() {
         });
         printf("bench gemm %-10s %s M=%lld N=%d K=%d: %.3f ms  %.1f TFLOP/s\n", s.name, dtn(dt), (long long)M, s.N, s.K, ms, 2.0 * M * s.N * s.K / ms * 1e-9);
     }
-    {
+    if (!quick) {
         const int B = 256, T = 197, heads = 12, d = 768;
         auto Q = randn((size_t)B * T * 3 * d);
         auto Qp = pack(Q, LECLIP_BF16);
