@@ -10,6 +10,7 @@
 // with V^T fragments produced by the transposing LDS read ds_read_b64_tr_b16 from the row-major V image.
 // LDS swizzles: K rows are read with ds_read_b128 (chunk ^= (row>>1)&7), V rows with the tr read (64-B half ^= (row>>1)&1).
 #include "leclip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -21,6 +22,167 @@ struct AttnArgs {
     float scale_log2e;  // scale * log2(e)
     int causal;
 };
+
+// One 32-query block of one (batch, head): S^T = K.Q^T, masked softmax over keys, O^T = V^T.P^T, store.
+// sK / sV: the head's K and V images in LDS (swizzled as described above); `base` points at q[b, 0, head, 0].
+// Q fragments of a 32-query block (MFMA B operand): lane (r = lane&31, h = lane>>5) holds Q[q0 + r][16s + 8h + j].
+template <typename T>
+__device__ __forceinline__ void attn_load_q(const AttnArgs& a, const T* base, int qb, int lane,
+                                            typename VecOf<T>::v8 (&qf)[4]) {
+    typedef typename VecOf<T>::v8 v8;
+    const int qi = qb * 32 + (lane & 31);
+    const int qrow = qi < a.T ? qi : a.T - 1;
+    const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + s * 16);
+}
+
+// STORE_ALL: lanes whose query index is past T store the (identical) result of the clamped row T-1 instead of being
+// masked off, so every wave issues the same number of store instructions (counted vmcnt waits in the pipelined kernel).
+template <typename T, int NKT, bool STORE_ALL>
+__device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, const char* sV,
+                                            const typename VecOf<T>::v8 (&qf)[4], T* obase, int qb, int lane) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int li = lane & 15, dgrp = (lane >> 4) & 1;
+    const char* kbase[4];
+    const char* vbase[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kbase[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+        const int qi = qb * 32 + fr;
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        f32x16 sc[NKT];
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+            // key row kt*32 + fr: the swizzle term ((row>>1)&7) depends on fr only, so each k-step has one
+            // lane address and the tile index is an immediate offset
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const v8 kf = *(const v8*)(kbase[s] + kt * 4096);
+                sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
+            }
+        }
+        // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
+        const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt) {
+            // a key tile needs masking only if it reaches past the last valid key (wave-uniform test): for the
+            // unmasked image tower that is the final tile alone
+            const bool partial = a.causal || (kt * 32 + 31 > a.T - 1);
+            if (partial) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    sc[kt][r] = key <= klimit ? sc[kt][r] : -3.0e38f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+        const float mb = mx * a.scale_log2e;
+#pragma unroll
+        for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                // v_exp_f32 directly: arguments are <= 0, results below 2^-126 flush to 0 (masked keys: exactly 0)
+                const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], a.scale_log2e, -mb));
+                sc[kt][r] = p;
+                sum += p;
+            }
+        sum += __shfl_xor(sum, 32);
+        const float inv = 1.0f / sum;
+
+        // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+        if constexpr (!STORE_ALL) {
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    v8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        v8 vf;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            // key = kt*32 + 16*s2 + 8u + 4h + (li>>2), d0 = 32i + 16*dgrp + 4*(li&3); the 64-byte swizzle
+                            // bit ((key>>1)&1) is (li>>3)&1: lane-constant, folded into vbase[i]
+                            const v4 t4 = lds_read_tr16((const T*)(vbase[i] + (kt * 32 + 16 * s2 + 8 * u) * 128));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vf[4 * u + e] = t4[e];
+                        }
+                        o[i] = mfma_32x32x16(vf, pf, o[i]);
+                    }
+                }
+            }
+        } else {
+            // Pipelined kernel: LDS-DMA for the next head is in flight, and hipcc puts s_waitcnt vmcnt(0) in front of the
+            // ds_read_b64_tr_b16 *builtin* (it cannot see that the read does not alias the DMA target).  The same
+            // instruction through inline asm is invisible to that pass; its completion is then ours to wait for
+            // (lgkmcnt(0) + sched_barrier before the consuming MFMAs), software-pipelined one step ahead.
+            typedef __attribute__((ext_vector_type(2))) int i32x2;
+            const unsigned va0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vbase[0];
+            const unsigned va1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vbase[1];
+            i32x2 vr[2][4];   // [parity][i*2 + u]
+#define TR_ISSUE(par, step)                                                                                          \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int u = 0; u < 2; ++u)               \
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
+                             : "=v"(vr[par][i * 2 + u])                                                               \
+                             : "v"(i ? va1 : va0), "n"((((step) >> 1) * 32 + 16 * ((step) & 1) + 8 * u) * 128));
+            TR_ISSUE(0, 0)
+#pragma unroll
+            for (int st = 0; st < 2 * NKT; ++st) {
+                const int kt = st >> 1, s2 = st & 1, par = st & 1;
+                v8 pf;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                v8 vf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    typedef __attribute__((ext_vector_type(4))) int i32x4;
+                    i32x4 w;
+                    w[0] = vr[par][i * 2][0]; w[1] = vr[par][i * 2][1]; w[2] = vr[par][i * 2 + 1][0]; w[3] = vr[par][i * 2 + 1][1];
+                    vf[i] = __builtin_bit_cast(v8, w);
+                }
+                if (st + 1 < 2 * NKT) {
+                    if (par == 0) { TR_ISSUE(1, st + 1) } else { TR_ISSUE(0, st + 1) }
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i) o[i] = mfma_32x32x16(vf[i], pf, o[i]);
+            }
+#undef TR_ISSUE
+        }
+        // ---- store: lane owns query qi; registers 4g..4g+3 are 4 consecutive d
+        if (STORE_ALL || qi < a.T) {
+            T* op = obase + (int64_t)(STORE_ALL ? qrow : qi) * a.ld_out;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    v4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
+                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
+                }
+        }
+}
 
 template <typename T, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
@@ -53,106 +215,104 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    const int fr = lane & 31, fh = lane >> 5;
     const int nqb = (a.T + 31) >> 5;
-    const int li = lane & 15, dgrp = (lane >> 4) & 1;
-    const char* kbase[4];
-    const char* vbase[2];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kbase[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+    T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
     for (int qb = wave; qb < nqb; qb += 4) {
-        const int qi = qb * 32 + fr;
-        const int qrow = qi < a.T ? qi : a.T - 1;
-        // Q fragments (B operand): Q[q][16s + 8h + j]
         v8 qf[4];
-        {
-            const T* qp = base + (int64_t)qrow * a.ld_qkv + fh * 8;
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qf[s] = *(const v8*)(qp + s * 16);
-        }
-        f32x16 sc[NKT];
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
-            // key row kt*32 + fr: the swizzle term ((row>>1)&7) depends on fr only, so each k-step has one
-            // lane address and the tile index is an immediate offset
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const v8 kf = *(const v8*)(kbase[s] + kt * 4096);
-                sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
-            }
-        }
-        // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
-        const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
-        float mx = -3.0e38f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
-                sc[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float sum = 0.f;
-        const float mb = mx * a.scale_log2e;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float p = exp2f(sc[kt][r] * a.scale_log2e - mb);  // masked: exp2(-huge) = 0
-                sc[kt][r] = p;
-                sum += p;
-            }
-        sum += __shfl_xor(sum, 32);
-        const float inv = 1.0f / sum;
+        attn_load_q<T>(a, base, qb, lane, qf);
+        attn_qblock<T, NKT, false>(a, sK, sV, qf, obase, qb, lane);
+    }
+}
 
-        // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
-        f32x16 o[2];
+// ---------------------------------------------------------------- pipelined kernel for many heads (ViT at large batch)
+// 512 threads = 8 waves, one persistent workgroup per CU walking (batch, head) pairs.  K/V of head i+1 stream into the
+// second LDS buffer by LDS-DMA (global_load_lds_dwordx4; the swizzles are applied to the per-lane SOURCE address, rows past
+// T re-read row T-1: masked keys / zero probabilities make them inert) and its Q fragments into registers while head i
+// is computed; wave w owns query block w.  The wait is counted: every wave ends a head with exactly 8 output stores,
+// so "all but the newest 8" retires its share of the next head's K/V and Q without draining those stores.  One barrier
+// per head.
+template <typename T, int NKT>
+__global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int total_heads) {
+    typedef typename VecOf<T>::v8 v8;
+    constexpr int TP = NKT * 32, BUF = TP * 128;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][K | V][BUF] + [8 waves][4 KiB Q]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int d_model = a.heads * 64;
+    const int last = total_heads - 1;
+
+    auto head_base = [&](int hd) {
+        const int b = hd / a.heads, h = hd - b * a.heads;
+        return (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+    };
+    // K then V, TP/8 pieces of 8 rows x 128 B each; wave w takes pieces w, w+8, ... (NKT per wave)
+    auto issue = [&](const T* base, int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < NKT; ++kt) {
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                v8 pf;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    v8 vf;
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        // key = kt*32 + 16*s2 + 8u + 4h + (li>>2), d0 = 32i + 16*dgrp + 4*(li&3); the 64-byte swizzle
-                        // bit ((key>>1)&1) is (li>>3)&1: lane-constant, folded into vbase[i]
-                        const v4 t4 = lds_read_tr16((const T*)(vbase[i] + (kt * 32 + 16 * s2 + 8 * u) * 128));
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) vf[4 * u + e] = t4[e];
-                    }
-                    o[i] = mfma_32x32x16(vf, pf, o[i]);
-                }
-            }
+        for (int u = 0; u < NKT; ++u) {
+            const int pc = wave + 8 * u;
+            const int isv = pc >= TP / 8 ? 1 : 0;
+            const int piece = pc - isv * (TP / 8);
+            const int row = piece * 8 + (lane >> 3);
+            const int p = lane & 7;
+            const int c = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+            const int grow = row < a.T ? row : a.T - 1;
+            const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + c * 8;
+            __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(smem + buf * 2 * BUF + isv * BUF + piece * 1024), 16, 0, 0);
         }
-        // ---- store: lane owns query qi; registers 4g..4g+3 are 4 consecutive d
-        if (qi < a.T) {
-            T* op = (T*)a.out + ((int64_t)b * a.T + qi) * a.ld_out + h * 64;
+    };
+
+    // Q of the wave's own 32-query block also travels by LDS-DMA into a wave-private 4 KiB image (K-style swizzle), so the
+    // loop holds no VGPR-destination global load: hipcc then inserts no vmcnt waits of its own and the counted waits below
+    // are the only ones.
+    char* sQ = smem + 4 * BUF + wave * 4096;
+    auto issue_q = [&](const T* base) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    v4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
-                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
-                }
+        for (int u = 0; u < 4; ++u) {
+            const int row = u * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            const int qi = wave * 32 + row;
+            const int grow = qi < a.T ? qi : a.T - 1;
+            __builtin_amdgcn_global_load_lds((const void*)(base + (int64_t)grow * a.ld_qkv + c * 8), LDS_PTR(sQ + u * 1024), 16, 0, 0);
         }
+    };
+    const char* qrd = sQ + (lane & 31) * 128;
+    const int qsw = ((lane & 31) >> 1) & 7, qh = lane >> 5;
+
+    int hd = blockIdx.x;
+    const bool active = wave * 32 < a.T;   // wave-uniform
+    {
+        const T* base = head_base(hd);
+        issue(base, 0);
+        if (active) issue_q(base);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    for (int it = 0; hd < total_heads; ++it) {
+        const int cur = it & 1;
+        const int nxt = hd + gridDim.x;
+        const int nxt_c = nxt < total_heads ? nxt : last;   // past the end: a harmless re-load keeps the op counts uniform
+        // One barrier per head: every wave has (a) finished head it-1, so buffer cur^1 may be overwritten, and
+        // (b) passed the counted wait at the end of its previous iteration, so every share of head `hd` is in buffer cur.
+        __builtin_amdgcn_s_barrier();
+        const T* nb = head_base(nxt_c);
+        if (active) {
+            v8 q[4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) q[s] = *(const v8*)(qrd + (((2 * s + qh) ^ qsw) << 4));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Q fragments are in registers: the Q image may be refilled
+            issue(nb, cur ^ 1);
+            issue_q(nb);
+            const int b = hd / a.heads, h = hd - b * a.heads;
+            T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
+            attn_qblock<T, NKT, true>(a, smem + cur * 2 * BUF, smem + cur * 2 * BUF + BUF, q, obase, wave, lane);
+            // Everything older than this head's 8 output stores has completed: the next head's K/V share and Q image
+            // (issued a whole head ago) are in, without draining the stores just issued.
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            // a wave without a query block (wave 7 when T <= 224) only moves its share of K/V
+            issue(nb, cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        hd = nxt;
     }
 }
 
@@ -221,6 +381,24 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
 template <typename T>
 int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     const unsigned grid = (unsigned)(B * a.heads);
+    static const int force_pipe = [] { const char* e = getenv("LECLIP_ATTN_PIPE"); return e ? atoi(e) : -1; }();   // test hook
+    const bool pipe_ok = a.T > 192 && a.T <= 224;   // 7 query blocks for 8 waves
+    if (pipe_ok && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
+        static int n_cu = 0;
+        static bool attr_set = false;
+        if (!n_cu) {
+            int dev = 0;
+            (void)hipGetDevice(&dev);
+            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+        }
+        constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_heads_kernel<T, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_heads_kernel<T, 7>), dim3(grid < (unsigned)n_cu ? grid : (unsigned)n_cu), dim3(512), LDSB, s, a, (int)grid);
+        return leclip_check_launch("attn_heads_kernel");
+    }
     if (a.T <= 32) hipLaunchKernelGGL((attn_rows_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a);
     else if (a.T <= 96) hipLaunchKernelGGL((attn_rows_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a);
     else if (a.T <= 224) hipLaunchKernelGGL((attn_rows_kernel<T, 7>), dim3(grid), dim3(256), 0, s, a);

@@ -83,6 +83,21 @@ int ln_dispatch_out(const void* x, const float* g, const float* b, void* y, int6
     return leclip_check_launch("layernorm_kernel");
 }
 
+template <typename TP>
+__device__ __forceinline__ float proj_column(const TP* __restrict__ p, const float* __restrict__ xn, int dim, int E) {
+    float acc = 0.f;
+    int k = 0;
+    for (; k + 8 <= dim; k += 8) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = (float)p[(int64_t)(k + u) * E];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = fmaf(xn[k + u], w[u], acc);
+    }
+    for (; k < dim; ++k) acc = fmaf(xn[k], (float)p[(int64_t)k * E], acc);
+    return acc;
+}
+
 // ------------------------------------------------------------------------- gather + LayerNorm + projection
 // One workgroup per output row: the gathered row is normalised into LDS (fp32), then thread e accumulates
 // out[e] = sum_k xn[k] * proj[k][e] reading proj rows coalesced across threads.
@@ -108,51 +123,35 @@ __global__ __launch_bounds__(256) void gather_ln_proj_kernel(const void* __restr
     const float rstd = rsqrtf((red[4] + red[5] + red[6] + red[7]) / (float)dim + eps);
     for (int k = tid; k < dim; k += 256) xn[k] = (xn[k] - mean) * rstd * gamma[k] + beta[k];
     __syncthreads();
+    // thread e walks proj[:, e] (coalesced across threads), 8 independent loads in flight per step
     for (int e = tid; e < E; e += 256) {
         float acc = 0.f;
-        if (pdt == LECLIP_F32) { const float* p = (const float*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], p[(int64_t)k * E], acc); }
-        else if (pdt == LECLIP_F16) { const f16_t* p = (const f16_t*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], (float)p[(int64_t)k * E], acc); }
-        else { const bf16_t* p = (const bf16_t*)proj + e; for (int k = 0; k < dim; ++k) acc = fmaf(xn[k], (float)p[(int64_t)k * E], acc); }
+        if (pdt == LECLIP_F32) acc = proj_column<float>((const float*)proj + e, xn, dim, E);
+        else if (pdt == LECLIP_F16) acc = proj_column<f16_t>((const f16_t*)proj + e, xn, dim, E);
+        else acc = proj_column<bf16_t>((const bf16_t*)proj + e, xn, dim, E);
         out[(int64_t)blockIdx.x * E + e] = acc;
     }
 }
 
 // --------------------------------------------------------------------- L2 normalise + scaled cosine logits
-// Workgroup = 4 waves = 4 image rows; the text matrix [C,D] streams from L2.  Per (image, class) one wave dot
-// product would waste lanes, so each wave keeps its image row in registers (D/64 per lane) and loops classes.
-constexpr int LG_MAXV = 32;  // D <= 2048
+// One thread per (image, class): it streams both 2 KiB feature rows with 16-byte loads (all of it L1/L2 resident: the
+// two matrices are 0.7 MB) and keeps three dot products, <i,t>, <i,i>, <t,t>; the result is
+// (scale * <i,t>) / (||i|| ||t||).  21 MFLOP at B = 256: pure latency, so maximum thread-level parallelism.
 __global__ __launch_bounds__(256) void l2norm_logits_kernel(const float* __restrict__ img, const float* __restrict__ txt,
                                                             float* __restrict__ logits, int64_t B, int C, int D, float scale) {
-    extern __shared__ float tinv[];  // [C] inverse text norms
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int c = wave; c < C; c += 4) {
-        float s = 0.f;
-        for (int k = lane; k < D; k += 64) { const float v = txt[(int64_t)c * D + k]; s = fmaf(v, v, s); }
-        s = wave_sum(s);
-        if (lane == 0) tinv[c] = 1.0f / sqrtf(s);
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * C) return;
+    const int64_t b = idx / C;
+    const int c = (int)(idx - b * C);
+    const f32x4* ip = (const f32x4*)(img + b * D);
+    const f32x4* tp = (const f32x4*)(txt + (int64_t)c * D);
+    float it = 0.f, ii = 0.f, tt = 0.f;
+    for (int k = 0; k < D / 4; ++k) {
+        const f32x4 x = ip[k], y = tp[k];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { it = fmaf(x[e], y[e], it); ii = fmaf(x[e], x[e], ii); tt = fmaf(y[e], y[e], tt); }
     }
-    __syncthreads();
-    const int64_t b = (int64_t)blockIdx.x * 4 + wave;
-    if (b >= B) return;
-    float x[LG_MAXV];
-    float s = 0.f;
-    const int nv = D >> 6;
-#pragma unroll
-    for (int i = 0; i < LG_MAXV; ++i)
-        if (i < nv) { x[i] = img[b * D + i * 64 + lane]; s = fmaf(x[i], x[i], s); }
-    const float si = scale / sqrtf(wave_sum(s));
-#pragma unroll
-    for (int i = 0; i < LG_MAXV; ++i)
-        if (i < nv) x[i] *= si;                      // (scale * img/||img||) first, as `a * b @ c` parses
-    for (int c = 0; c < C; ++c) {
-        float d = 0.f;
-        const float ti = tinv[c];
-#pragma unroll
-        for (int i = 0; i < LG_MAXV; ++i)
-            if (i < nv) d = fmaf(x[i], txt[(int64_t)c * D + i * 64 + lane] * ti, d);
-        d = wave_sum(d);
-        if (lane == 0) logits[b * C + c] = d;
-    }
+    logits[idx] = (scale * it) / (sqrtf(ii) * sqrtf(tt));
 }
 
 // ------------------------------------------------------------------------------ embeddings / prompt assembly
@@ -271,10 +270,10 @@ extern "C" int leclip_gather_ln_proj_fwd(const void* x, const int64_t* row_index
 extern "C" int leclip_l2norm_logits_fwd(const float* img, const float* txt, float* logits, int64_t B, int C, int D,
                                         float scale, void* stream) {
     if (!img || !txt || !logits || B <= 0 || C <= 0 || D <= 0) { leclip_set_error("logits: null pointer or bad size"); return LECLIP_E_INVALID; }
-    if (D % 64 != 0 || D > 64 * LG_MAXV || C > 8192) {
-        leclip_set_error("logits: D=%d must be a multiple of 64 and <= %d; C=%d <= 8192", D, 64 * LG_MAXV, C); return LECLIP_E_UNSUPPORTED;
+    if (D % 4 != 0 || ((uintptr_t)img & 15) || ((uintptr_t)txt & 15)) {
+        leclip_set_error("logits: D=%d must be a multiple of 4 and the feature matrices 16-byte aligned", D); return LECLIP_E_UNSUPPORTED;
     }
-    hipLaunchKernelGGL(l2norm_logits_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), C * sizeof(float), (hipStream_t)stream,
+    hipLaunchKernelGGL(l2norm_logits_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        img, txt, logits, B, C, D, scale);
     return leclip_check_launch("l2norm_logits_kernel");
 }

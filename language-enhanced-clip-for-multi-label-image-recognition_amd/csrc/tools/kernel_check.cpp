@@ -197,6 +197,8 @@ int main(int argc, char** argv) {
     check_gemm(777, 192, 160, LECLIP_F32, LECLIP_F32, LECLIP_F32, 1, true, true);
     for (int dt : {LECLIP_BF16, LECLIP_F16, LECLIP_F32}) {
         check_attn(2, 197, 3, dt, 0);
+        check_attn(3, 224, 2, dt, 0);
+        check_attn(2, 200, 2, dt, 1);
         check_attn(3, 77, 2, dt, 1);
         check_attn(2, 17, 2, dt, 0);
         check_attn(1, 50, 1, dt, 1);
