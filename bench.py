@@ -199,7 +199,7 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
             n += 1
     ref = np.concatenate(ref_logits)
     hip = np.concatenate(hip_logits)
-    labels = synth.make_labels_from_logits(ref, seed=7, topk=3, noise=0.5)
+    labels = synth.make_labels_from_logits(ref, seed=7, pos_frac=0.1, noise=0.5)
     base = {"value": n * cb / spent, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": f"{n} batches of {cb} images, fp32 torch-CPU oracle forward + logits, {spent:.1f} s of CPU work, "
                       f"torch {torch.__version__}, {cores} threads"}

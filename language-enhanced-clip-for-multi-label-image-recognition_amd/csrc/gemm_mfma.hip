@@ -207,6 +207,9 @@ int launch_mfma(const GemmArgs& a, hipStream_t s) {
 int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                            const EpiParams& epi, hipStream_t s);
 bool leclip_gemm256_eligible(int64_t M, int N, int K);
+int leclip_gemm256_cus();
+int launch_128(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi,
+               int ab_dtype, hipStream_t s);
 int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                           const EpiParams& epi, int ab_dtype, hipStream_t s);
 
@@ -229,7 +232,30 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
             return LECLIP_E_INVALID;
         }
     }
-    if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
+    if (leclip_gemm256_eligible(M, N, K)) {
+        // Wave quantisation: the persistent 256x256 kernel runs whole rounds of n_cu tiles.  When the last round
+        // would be less than half full, the trailing tile rows go to the 128x128 kernel instead (2 workgroups per CU,
+        // finer tiles): e.g. N = 768 at M = 50432 is 591 tiles = 2.3 rounds -> 170 tile rows + 6912 rows.
+        const int n_cu = leclip_gemm256_cus();
+        const int64_t tile_rows = (M + 255) / 256, tn = N / 256, tiles = tile_rows * tn;
+        const int64_t rounds = tiles / n_cu, rem = tiles % n_cu;
+        const int64_t full_rows = rounds * n_cu / tn;
+        if (rounds >= 1 && rem > 0 && 2 * rem <= n_cu && !epi.rowmap_P && full_rows > 0 && full_rows * 256 < M) {
+            const int64_t M1 = full_rows * 256;
+            int rc = leclip_gemm256_launch(A, W, M1, N, K, lda, ldw, epi, ab_dtype, s);
+            if (rc) return rc;
+            EpiParams e2 = epi;
+            e2.out = (char*)epi.out + M1 * epi.ldy * dtype_size(epi.out_dt);
+            if (epi.res) e2.res = (const char*)epi.res + M1 * epi.ldr * dtype_size(epi.res_dt);
+            return launch_128((const char*)A + M1 * lda * 2, W, M - M1, N, K, lda, ldw, e2, ab_dtype, s);
+        }
+        return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
+    }
+    return launch_128(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
+}
+
+int launch_128(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi,
+               int ab_dtype, hipStream_t s) {
     GemmArgs a;
     a.A = A; a.W = W; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldw = ldw; a.epi = epi;
     const int64_t tiles_m = (M + BM - 1) / BM;

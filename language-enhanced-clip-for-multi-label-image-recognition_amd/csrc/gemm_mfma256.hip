@@ -26,6 +26,8 @@
 #include "leclip_common.h"
 #include <stdlib.h>
 
+int leclip_gemm256_cus();
+
 namespace {
 
 constexpr int TM = 256, TN = 256, TK = 64;
@@ -257,6 +259,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (!(g.dbg & 1)) {
             float* st = (float*)(smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
             const int wsw = ((lane >> 4) & 1) << 4;
+            // A 16-bit residual is fetched for the whole tile up front (16 x 16 B per lane): vmcnt retires in order, so a
+            // residual load issued between the passes would wait for the previous pass's stores to reach memory.
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            i32x4 rpre[16];
+            const bool res16 = e.res && e.res_dt != LECLIP_F32;
+            if (res16) {
+#pragma unroll
+                for (int qu = 0; qu < 16; ++qu) {
+                    int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
+                    m = m < g.M ? m : g.M - 1;
+                    const int64_t rrow = e.rowmap_P ? m % e.rowmap_P + 1 : m;
+                    rpre[qu] = *(const i32x4*)((const char*)e.res + (rrow * e.ldr + n) * 2);
+                }
+            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int h = q >> 2, i = q & 3;
@@ -291,11 +307,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) { vv[c] += r0[c]; vv[4 + c] += r1[c]; }
                         } else if (e.res_dt == LECLIP_BF16) {
-                            const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+                            const bf16x8 r8 = __builtin_bit_cast(bf16x8, rpre[q * 2 + u]);
 #pragma unroll
                             for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
                         } else {
-                            const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+                            const f16x8 r8 = __builtin_bit_cast(f16x8, rpre[q * 2 + u]);
 #pragma unroll
                             for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
                         }
@@ -335,12 +351,7 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-    }
+    const int n_cu = leclip_gemm256_cus();
     static const int cap = [] { const char* e = getenv("LECLIP_GEMM_GRID"); return e ? atoi(e) : 0; }();   // test hook: force multi-tile loops
     const int limit = cap > 0 ? cap : n_cu;
     const int grid = a.tiles_total < limit ? a.tiles_total : limit;   // one persistent workgroup per CU (160 KiB LDS each)
@@ -349,6 +360,16 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 }
 
 }  // namespace
+
+int leclip_gemm256_cus() {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
 
 // Shapes this kernel takes: N % 256 == 0, K % 64 == 0, K >= 128; worth it only when the grid fills the chip.
 bool leclip_gemm256_eligible(int64_t M, int N, int K) {

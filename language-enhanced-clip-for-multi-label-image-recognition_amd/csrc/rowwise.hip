@@ -222,6 +222,51 @@ __global__ void im2col_kernel(const void* __restrict__ image, void* __restrict__
         for (int k = 3 * P * P; k < Kp; ++k) store_elem(patches, odt, r * Kp + k, 0.f);
 }
 
+// P % 8 == 0: one thread per (patch row, 8 consecutive k): 8 pixels of one image row (32 B fp32 / 16 B 16-bit load),
+// one 16-byte store; consecutive threads write consecutive chunks of the patch matrix (fully coalesced stores).
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void im2col8_kernel(const TI* __restrict__ image, TO* __restrict__ patches, int64_t n_rows,
+                                                      int R, int P, int Kp) {
+    const int chunks = Kp >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * chunks) return;
+    const int64_t r = i / chunks;
+    const int k0 = (int)(i - r * chunks) * 8;
+    const int G = R / P;
+    float v[8];
+    if (k0 < 3 * P * P) {
+        const int c = k0 / (P * P), rem = k0 - c * P * P, py = rem / P, px0 = rem - py * P;
+        const int gx = (int)(r % G), gy = (int)((r / G) % G);
+        const int64_t b = r / ((int64_t)G * G);
+        const TI* src = image + ((b * 3 + c) * R + (gy * P + py)) * (int64_t)R + gx * P + px0;
+#pragma unroll
+        for (int e = 0; e < 8; e += 4) {
+            const f32x4 t = load4<TI>(src + e);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[e + u] = t[u];
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = 0.f;
+    }
+    TO* dst = patches + r * Kp + k0;
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+        f32x4 t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = v[e + u];
+        store4<TO>(dst + e, t);
+    }
+}
+
+template <typename TI>
+void im2col8_out(const void* image, void* patches, int64_t n_rows, int R, int P, int Kp, int odt, hipStream_t s) {
+    const dim3 grid((unsigned)((n_rows * (Kp / 8) + 255) / 256)), block(256);
+    if (odt == LECLIP_F32) hipLaunchKernelGGL((im2col8_kernel<TI, float>), grid, block, 0, s, (const TI*)image, (float*)patches, n_rows, R, P, Kp);
+    else if (odt == LECLIP_F16) hipLaunchKernelGGL((im2col8_kernel<TI, f16_t>), grid, block, 0, s, (const TI*)image, (f16_t*)patches, n_rows, R, P, Kp);
+    else hipLaunchKernelGGL((im2col8_kernel<TI, bf16_t>), grid, block, 0, s, (const TI*)image, (bf16_t*)patches, n_rows, R, P, Kp);
+}
+
 __global__ void class_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, void* __restrict__ X,
                                   int T, int width, int xdt) {
     const int64_t b = blockIdx.x;
@@ -332,8 +377,15 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
     hipStream_t s = (hipStream_t)stream;
     const int G = R / P, T = G * G + 1, Kp = patch_kp(P, w_dtype);
     const int64_t total = B * G * G * 3 * P;
-    hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp,
-                       (int)img_dtype, (int)w_dtype);
+    if (P % 8 == 0 && ((uintptr_t)image & 15) == 0) {
+        const int64_t n_rows = B * G * G;
+        if (img_dtype == LECLIP_F32) im2col8_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else if (img_dtype == LECLIP_F16) im2col8_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else im2col8_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+    } else {
+        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp,
+                           (int)img_dtype, (int)w_dtype);
+    }
     int rc = leclip_check_launch("im2col_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(class_rows_kernel, dim3((unsigned)B), dim3(256), 0, s, class_emb, pos, X, T, width, (int)x_dtype);
