@@ -300,6 +300,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                     if ((g.dbg & 2) && vv[0] != 12345.678f) continue;
                     int64_t orow = m, rrow = m;
                     if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+                    if (g.dbg & 8) orow = (m & 15) + 16 * (blockIdx.x & 255);   // diagnostic: cache-resident store footprint
                     if (e.res) {
                         if (e.res_dt == LECLIP_F32) {
                             const float* rp = (const float*)e.res + rrow * e.ldr + n;

