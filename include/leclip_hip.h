@@ -75,7 +75,8 @@ int leclip_patch_embed_fwd(const void* image, const void* Wp, const float* class
  * Replaces the scaled-dot-product step inside nn.MultiheadAttention as called at clip/model.py:221-223
  * (mask: clip/model.py:364-370 additive -inf strictly above the diagonal for the text tower).
  * qkv [B*T, 3*heads*64] rows = tokens (batch-major), columns q|k|v each heads*64 (in_proj order); out [B*T, heads*64].
- * head_dim must be 64.  F16/BF16: T <= 224 (fused single-pass MFMA kernel) or any T (streaming kernel); F32: T <= 304. */
+ * head_dim must be 64.  F16/BF16: T <= 224 single-pass MFMA kernels (pipelined across heads when there are many),
+ * T <= 640 streaming (online-softmax) kernel; F32: T <= 588. */
 int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
                          int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale,
                          leclip_dtype dtype, void* stream);

@@ -316,17 +316,157 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     }
 }
 
+// ---------------------------------------------------------------- streaming kernel for long sequences (ViT-L/14@336: T = 577)
+// One 512-thread workgroup per (batch, head); the head's whole K and V (T <= 640: 2 x 80 KiB) sit in LDS, each wave
+// owns 32-query blocks and walks the keys in chunks of 4 tiles (128 keys) with the online-softmax recurrence: running
+// row maximum m and normaliser l live in the two lanes that hold a query, O^T accumulators are rescaled by
+// exp2(scale*(m_old - m_new)) when the maximum moves.  Same MFMA formulation as attn_qblock (S^T = K.Q^T, P fed back
+// as the B operand, V^T by ds_read_b64_tr_b16).
+constexpr int STREAM_TMAX = 640;
+
+template <typename T>
+__global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K [TP][128 B] | V [TP][128 B]
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+    const int d_model = a.heads * 64;
+    const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+    for (int r = tid >> 3; r < TP; r += 64) {
+        const int c = tid & 7;
+        v8 kv, vv;
+        if (r < a.T) {
+            const T* row = base + (int64_t)r * a.ld_qkv;
+            kv = *(const v8*)(row + d_model + c * 8);
+            vv = *(const v8*)(row + 2 * d_model + c * 8);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { kv[i] = (T)0.f; vv[i] = (T)0.f; }
+        }
+        *(v8*)(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
+        *(v8*)(sV + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vv;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int li = lane & 15, dgrp = (lane >> 4) & 1;
+    const char* kbase[4];
+    const char* vbase[2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kbase[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+
+    const int nqb = (a.T + 31) >> 5, nchunk = TP >> 7;
+    T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
+    for (int qb = wave; qb < nqb; qb += 8) {
+        v8 qf[4];
+        attn_load_q<T>(a, base, qb, lane, qf);
+        const int qi = qb * 32 + fr;
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        const int klimit = a.causal ? qrow : a.T - 1;
+        float m_run = -3.0e38f, l_run = 0.f;
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int key0 = ch * 128;
+            if (a.causal && key0 > qb * 32 + 31) break;   // wave-uniform: every key of this chunk is masked for the block
+            f32x16 sc[4];
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const v8 kf = *(const v8*)(kbase[s] + (key0 + kt * 32) * 128);
+                    sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
+                }
+            }
+            float mx = m_run;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
+                    sc[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * a.scale_log2e);   // first chunk: exp2(-huge) = 0
+            m_run = mx;
+            const float mb = mx * a.scale_log2e;
+            float sum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], a.scale_log2e, -mb));
+                    sc[kt][r] = p;
+                    sum += p;
+                }
+            sum += __shfl_xor(sum, 32);
+            l_run = l_run * alpha + sum;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    v8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        v8 vf;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const v4 t4 = lds_read_tr16((const T*)(vbase[i] + (key0 + kt * 32 + 16 * s2 + 8 * u) * 128));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) vf[4 * u + e] = t4[e];
+                        }
+                        o[i] = mfma_32x32x16(vf, pf, o[i]);
+                    }
+                }
+        }
+        const float inv = 1.0f / l_run;
+        if (qi < a.T) {
+            T* op = obase + (int64_t)qi * a.ld_out;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    v4 w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
+                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
+                }
+        }
+    }
+}
+
 // ---------------------------------------------------------------- fp32 validation kernel
 // One workgroup per (batch, head), K and V in LDS as fp32 (rows padded to 65 floats), one query row per wave at
 // a time: lanes own keys for the scores, then own output dimensions for P.V.  T <= 304 (LDS budget).
-constexpr int F32_TMAX = 304;
+constexpr int F32_TMAX = 304;    // K and V both in LDS
+constexpr int F32_TMAX_VG = 588; // K in LDS, V read from global memory (L2-resident: 64 lanes x 4 B = one 256-B row per key)
 
-__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a, int v_global) {
     extern __shared__ __attribute__((aligned(16))) float smf[];
-    float* sK = smf;                       // [T][65]
-    float* sV = smf + (size_t)a.T * 65;    // [T][65]
-    float* sP = sV + (size_t)a.T * 65;     // [4][TPAD]
     const int TPAD = (a.T + 63) & ~63;
+    float* sK = smf;                                             // [T][65]
+    float* sV = smf + (size_t)a.T * 65;                          // [T][65] unless v_global
+    float* sP = v_global ? sV : sV + (size_t)a.T * 65;           // [4][TPAD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
     const int d_model = a.heads * 64;
@@ -334,18 +474,19 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
     for (int i = tid; i < a.T * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
         sK[r * 65 + c] = base[(int64_t)r * a.ld_qkv + d_model + c];
-        sV[r * 65 + c] = base[(int64_t)r * a.ld_qkv + 2 * d_model + c];
+        if (!v_global) sV[r * 65 + c] = base[(int64_t)r * a.ld_qkv + 2 * d_model + c];
     }
     __syncthreads();
     const float scale = a.scale_log2e * 0.6931471805599453f;
     float* myP = sP + wave * TPAD;
+    constexpr int NKK = (F32_TMAX_VG + 63) / 64;
     for (int q = wave; q < a.T; q += 4) {
         const float qd = base[(int64_t)q * a.ld_qkv + lane];   // q[d = lane]
         const int klimit = a.causal ? q : a.T - 1;
-        float sloc[(F32_TMAX + 63) / 64];
+        float sloc[NKK];
         float mx = -3.0e38f;
 #pragma unroll
-        for (int kk = 0; kk < (F32_TMAX + 63) / 64; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
             const int key = kk * 64 + lane;
             float s = -3.0e38f;
             if (kk * 64 < a.T) {
@@ -360,7 +501,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
         mx = wave_max(mx);
         float sum = 0.f;
 #pragma unroll
-        for (int kk = 0; kk < (F32_TMAX + 63) / 64; ++kk) {
+        for (int kk = 0; kk < NKK; ++kk) {
             const int key = kk * 64 + lane;
             if (kk * 64 < a.T) {
                 const float p = key <= klimit ? expf(sloc[kk] - mx) : 0.f;
@@ -372,7 +513,12 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         float acc = 0.f;
-        for (int key = 0; key <= klimit; ++key) acc = fmaf(myP[key], sV[key * 65 + lane], acc);
+        if (v_global) {
+            const float* vp = base + 2 * d_model + lane;
+            for (int key = 0; key <= klimit; ++key) acc = fmaf(myP[key], vp[(int64_t)key * a.ld_qkv], acc);
+        } else {
+            for (int key = 0; key <= klimit; ++key) acc = fmaf(myP[key], sV[key * 65 + lane], acc);
+        }
         ((float*)a.out)[((int64_t)b * a.T + q) * a.ld_out + h * 64 + lane] = acc / sum;
         __builtin_amdgcn_wave_barrier();
     }
@@ -402,8 +548,17 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     if (a.T <= 32) hipLaunchKernelGGL((attn_rows_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a);
     else if (a.T <= 96) hipLaunchKernelGGL((attn_rows_kernel<T, 3>), dim3(grid), dim3(256), 0, s, a);
     else if (a.T <= 224) hipLaunchKernelGGL((attn_rows_kernel<T, 7>), dim3(grid), dim3(256), 0, s, a);
-    else {
-        leclip_set_error("attention: T=%d > 224 needs the streaming kernel (not built in this round)", a.T);
+    else if (a.T <= STREAM_TMAX) {
+        const int TP = (a.T + 127) & ~127;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_stream_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_TMAX * 256);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL((attn_stream_kernel<T>), dim3(grid), dim3(512), TP * 256, s, a, TP);
+        return leclip_check_launch("attn_stream_kernel");
+    } else {
+        leclip_set_error("attention: T=%d > %d is not supported in 16-bit modes", a.T, STREAM_TMAX);
         return LECLIP_E_UNSUPPORTED;
     }
     return leclip_check_launch("attn_rows_kernel");
@@ -428,16 +583,17 @@ extern "C" int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LECLIP_F32) {
-        if (T > F32_TMAX) { leclip_set_error("attention(f32): T=%d > %d", T, F32_TMAX); return LECLIP_E_UNSUPPORTED; }
-        if ((ld_qkv % 1) || ((uintptr_t)qkv & 3)) { leclip_set_error("attention(f32): misaligned"); return LECLIP_E_INVALID; }
+        if (T > F32_TMAX_VG) { leclip_set_error("attention(f32): T=%d > %d", T, F32_TMAX_VG); return LECLIP_E_UNSUPPORTED; }
+        if ((uintptr_t)qkv & 3) { leclip_set_error("attention(f32): misaligned"); return LECLIP_E_INVALID; }
         const int TPAD = (T + 63) & ~63;
-        const size_t lds = ((size_t)T * 65 * 2 + 4 * TPAD) * sizeof(float);
+        const int v_global = T > F32_TMAX;
+        const size_t lds = ((size_t)T * 65 * (v_global ? 1 : 2) + 4 * TPAD) * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, a);
+        hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, a, v_global);
         return leclip_check_launch("attn_f32_kernel");
     }
     if ((ld_qkv % 8) || (ld_out % 4) || ((uintptr_t)qkv & 15) || ((uintptr_t)out & 7)) {

@@ -336,3 +336,33 @@ def test_map_against_oracle(ops, dt, tol):
     m_ref, m_hip = mAP(labels, ref), mAP(labels, hip)
     print(f"mAP oracle {m_ref:.3f} hip[{dt}] {m_hip:.3f} max|dlogit| {np.abs(ref - hip).max():.3e}")
     assert m_ref > 30 and abs(m_ref - m_hip) <= tol
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_vit_l14_336_shapes_against_oracle(ops, golden_dir, dt):
+    """BASELINE config 5 geometry (ViT-L/14@336: 577 tokens, width 1024, 16 heads, patch 14, text width 768) at reduced
+    depth (2 + 2 blocks) against the CPU oracle: exercises the streaming attention kernel, the non-8-multiple patch
+    path and the K-padded patch GEMM."""
+    import dataclasses
+    from oracle import clip_oracle as co
+    arch = dataclasses.replace(synth.VIT_L14_336, vision_layers=2, transformer_layers=2)
+    sd = synth.make_state_dict(arch, seed=3, dist="cond")
+    m = _build(arch, 3, "cond", dt)
+    img = torch.from_numpy(synth.make_images(2, 336, seed=9))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    toks = torch.from_numpy(t["tokens_photo"][:7])
+    with torch.no_grad():
+        ref = co.clip_forward(img, toks, sd).numpy()
+        lpi, _ = m(img.to(DEV), toks.to(DEV))
+    band = _tol(dt, 1e-3, 2e-2, 1.5e-1)   # scale exp(logit_scale) = 14.3
+    np.testing.assert_allclose(lpi.cpu().numpy(), ref, atol=band, rtol=0)
+    if dt == torch.float32:
+        assert np.array_equal(lpi.cpu().numpy().argmax(1), ref.argmax(1))
+
+
+def test_train_caption_eval_entry_point(ops):
+    from leclip_amd import train_caption
+    out = train_caption.main(["--eval-only", "--trainer", "Caption_distill_double", "--backbone", "tiny", "--num-images", "48",
+                              "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)", "TRAINER.Caption.PREC", "fp32",
+                              "DATALOADER.TEST.BATCH_SIZE", "16"])
+    assert 0.0 < out["mAP"] <= 100.0
