@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 1
+#define LECLIP_ABI_VERSION 2
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -60,6 +60,24 @@ int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias
                                  int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy,
                                  leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
                                  leclip_dtype y_dtype, void* stream);
+
+/* The same GEMM with LayerNorm folded around it (16-bit operands only).
+ *  - ln_stats != NULL: A holds the UN-normalised rows x, W has gamma folded in (W'[n,k] = gamma[k] W[n,k]) and
+ *      Y = act(rstd[m] * (x . W'^T - mean[m] * ln_colsum[n]) + bias[n]) + residual,
+ *    with ln_stats [M][2] = (mean, rstd) per row, ln_colsum[n] = sum_k W'[n,k], bias[n] = sum_k beta[k] W[n,k] + b[n]:
+ *    algebraically clip/model.py:193-199 followed by F.linear, without materialising (or 16-bit rounding) LN(x).
+ *  - stats_out != NULL: additionally writes, per output row and 64-column block, (sum, sum of squares) of the rounded
+ *    outputs to stats_out [M][N/64][2]; leclip_ln_stats_finalize_fwd turns them into (mean, rstd) for the next
+ *    fused GEMM.  Plain stores in a fixed layout: deterministic, nothing to zero. */
+int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
+                             const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M, int N,
+                             int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
+                             leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream);
+/* (mean, rstd) per row: from the partial sums above (fixed summation order), or directly from rows of x. */
+int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
+                                 void* stream);
+int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, int dim, int64_t ldx, float eps, leclip_dtype x_dtype,
+                         void* stream);
 
 /* Patch embedding: X[b, 0, :] = class_emb + pos[0];  X[b, 1+p, :] = conv_{k=s=P, no bias}(image)[b, :, p] + pos[1+p].
  * Replaces clip/model.py:260-264 (conv1, reshape/permute, class-token concat, positional add).

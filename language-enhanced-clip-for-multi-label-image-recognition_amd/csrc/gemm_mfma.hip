@@ -139,6 +139,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
     }
+    float s8[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s8[c] = 0.f;
+    if (e.ln_stats) {
+        const f32x4 t0 = *(const f32x4*)(e.ln_colsum + n), t1 = *(const f32x4*)(e.ln_colsum + n + 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { s8[c] = t0[c]; s8[4 + c] = t1[c]; }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + crow;
@@ -147,47 +155,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
         if (m >= g.M) continue;
         float v[8];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { v[c] = v0[c] + b8[c]; v[4 + c] = v1[c] + b8[4 + c]; }
-        if (e.act == LECLIP_ACT_QUICKGELU) {
-#pragma unroll
-            for (int c = 0; c < 8; ++c) v[c] = v[c] / (1.0f + __expf(-1.702f * v[c]));   // x * sigmoid(1.702 x)
-        }
-        int64_t orow = m, rrow = m;
-        if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
-        if (e.res) {
-            if (e.res_dt == LECLIP_F32) {
-                const float* rp = (const float*)e.res + rrow * e.ldr + n;
-                const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
-            } else if (e.res_dt == LECLIP_BF16) {
-                const bf16x8 r8 = *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
-            } else {
-                const f16x8 r8 = *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
-#pragma unroll
-                for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
-            }
-        }
-        if (e.out_dt == LECLIP_F32) {
-            float* op = (float*)e.out + orow * e.ldy + n;
-            f32x4 o0, o1;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) { o0[c] = v[c]; o1[c] = v[4 + c]; }
-            *(f32x4*)op = o0;
-            *(f32x4*)(op + 4) = o1;
-        } else if (e.out_dt == LECLIP_BF16) {
-            bf16x8 o8;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
-            *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
-        } else {
-            f16x8 o8;
-#pragma unroll
-            for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
-            *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
-        }
+        for (int c = 0; c < 4; ++c) { v[c] = v0[c]; v[4 + c] = v1[c]; }
+        epi_chunk8<3>(e, m, n, v, b8, s8, i32x4{0, 0, 0, 0}, f32x2{0.f, 0.f});
     }
 }
 
@@ -247,6 +216,8 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
             EpiParams e2 = epi;
             e2.out = (char*)epi.out + M1 * epi.ldy * dtype_size(epi.out_dt);
             if (epi.res) e2.res = (const char*)epi.res + M1 * epi.ldr * dtype_size(epi.res_dt);
+            if (epi.ln_stats) e2.ln_stats = epi.ln_stats + 2 * M1;
+            if (epi.stats_out) e2.stats_out = epi.stats_out + M1 * epi.stats_slots * 2;
             return launch_128((const char*)A + M1 * lda * 2, W, M - M1, N, K, lda, ldw, e2, ab_dtype, s);
         }
         return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
@@ -288,5 +259,31 @@ extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const 
     EpiParams e;
     e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
     e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
+    return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
+}
+
+extern "C" int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
+                                        const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M,
+                                        int N, int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
+                                        leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream) {
+    if (!A || !W || !Y || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldy < N || (residual && ldr < N)) {
+        leclip_set_error("gemm_ln_fused: null pointer or inconsistent sizes (M=%lld N=%d K=%d)", (long long)M, N, K);
+        return LECLIP_E_INVALID;
+    }
+    if (ab_dtype == LECLIP_F32 || !dtype_ok(ab_dtype) || !dtype_ok(y_dtype) || (residual && !dtype_ok(res_dtype)) ||
+        (act != LECLIP_ACT_NONE && act != LECLIP_ACT_QUICKGELU)) {
+        leclip_set_error("gemm_ln_fused: 16-bit operands only (the fp32 parity path keeps LayerNorm as its own kernel)");
+        return LECLIP_E_UNSUPPORTED;
+    }
+    if ((ln_stats != nullptr) != (ln_colsum != nullptr) || (ln_stats && !bias) || (ln_colsum && ((uintptr_t)ln_colsum & 15)) ||
+        (stats_out && ((uintptr_t)stats_out & 7))) {
+        leclip_set_error("gemm_ln_fused: ln_stats, ln_colsum and bias go together; ln_colsum 16-byte, stats_out 8-byte aligned");
+        return LECLIP_E_INVALID;
+    }
+    EpiParams e;
+    e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
+    e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
+    e.ln_stats = ln_stats; e.ln_colsum = ln_colsum; e.stats_out = stats_out; e.stats_slots = N / 64;
     return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
 }

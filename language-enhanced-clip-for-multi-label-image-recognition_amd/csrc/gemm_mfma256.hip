@@ -145,7 +145,10 @@ struct PP {
     }
 };
 
-template <typename T>
+// PF selects what the epilogue prefetches into registers before its first store (compile-time, so that only one
+// prefetch array is ever allocated): 0 nothing, 1 the 16-bit residual of the tile, 2 the fused LayerNorm's (mean, rstd),
+// 3 generic (epilogue operands loaded inside the pass loop).
+template <typename T, int PF>
 __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -228,27 +231,71 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (g.dbg & 4) t = nk - 2 > 0 ? nk - 2 : 0;
         for (; t + 2 < nk; ++t) p.template ktile<0>(t);
         p.template ktile<1>(t);
+
         p.template ktile<2>(t + 1);
 
-        if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
-        PIN();
-        __syncthreads();                             // every wave is done reading the K-loop buffers
-
+        // Epilogue operands (bias, LayerNorm column sums, and - for the whole tile, 16 chunks per lane - the 16-bit
+        // residual or the fused LayerNorm's (mean, rstd)) are requested right after the last MFMA
+        // cluster: their latency overlaps the barriers that close the K-loop.
         const int64_t em0 = m0;
         const int en0 = n0;
-        const int vn = v + gridDim.x;
-        const bool more = vn < g.tiles_total;
-        float b8[8];
         const int crow = lane >> 3, ccol = (lane & 7) * 8;
         const int n = en0 + wn * 64 + ccol;
+        float b8[8], s8[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) b8[c] = 0.f;
+        for (int c = 0; c < 8; ++c) { b8[c] = 0.f; s8[c] = 0.f; }
         if (e.bias) {
             const f32x4 t0 = *(const f32x4*)(e.bias + n), t1 = *(const f32x4*)(e.bias + n + 4);
 #pragma unroll
             for (int c = 0; c < 4; ++c) { b8[c] = t0[c]; b8[4 + c] = t1[c]; }
         }
-        if (more) {
+        if (e.ln_stats) {
+            const f32x4 t0 = *(const f32x4*)(e.ln_colsum + n), t1 = *(const f32x4*)(e.ln_colsum + n + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { s8[c] = t0[c]; s8[4 + c] = t1[c]; }
+        }
+        i32x4 rpre[PF == 1 ? 16 : 1];
+        f32x2 lnpre[PF == 2 ? 16 : 1];
+        if constexpr (PF == 1) {
+#pragma unroll
+            for (int qu = 0; qu < 16; ++qu) {
+                int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
+                m = m < g.M ? m : g.M - 1;
+                const int64_t rrow = e.rowmap_P ? m % e.rowmap_P + 1 : m;
+                rpre[qu] = *(const i32x4*)((const char*)e.res + (rrow * e.ldr + n) * 2);
+            }
+        }
+        if constexpr (PF == 2) {
+#pragma unroll
+            for (int qu = 0; qu < 16; ++qu) {
+                int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
+                m = m < g.M ? m : g.M - 1;
+                lnpre[qu] = *(const f32x2*)(e.ln_stats + 2 * m);
+            }
+        }
+        PIN();
+        if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
+        PIN();
+        __syncthreads();                             // every wave is done reading the K-loop buffers
+
+        const int vn = v + gridDim.x;
+        const bool more = vn < g.tiles_total;
+        // Wait for them once, here, and launder the registers through empty asm statements so that hipcc sees their
+        // definitions as complete: otherwise it guards every use inside the store loop with a conservative vmcnt(0) (it
+        // cannot count the stores of the branchy store code; vmcnt retires loads and stores in order, so each such wait
+        // would drain the previous pass's stores - 16 store round trips per tile instead of one load round trip).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { asm volatile("" : "+v"(b8[c])); asm volatile("" : "+v"(s8[c])); }
+        if constexpr (PF == 1) {
+#pragma unroll
+            for (int qu = 0; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
+        }
+        if constexpr (PF == 2) {
+#pragma unroll
+            for (int qu = 0; qu < 16; ++qu) asm volatile("" : "+v"(lnpre[qu]));
+        }
+        if (more) {   // next tile's first K-tiles: their HBM/L2 latency overlaps this tile's epilogue
             tile_origin(vn, m0, n0);
             prologue(m0, n0);
         }
@@ -259,20 +306,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (!(g.dbg & 1)) {
             float* st = (float*)(smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
             const int wsw = ((lane >> 4) & 1) << 4;
-            // A 16-bit residual is fetched for the whole tile up front (16 x 16 B per lane): vmcnt retires in order, so a
-            // residual load issued between the passes would wait for the previous pass's stores to reach memory.
-            typedef __attribute__((ext_vector_type(4))) int i32x4;
-            i32x4 rpre[16];
-            const bool res16 = e.res && e.res_dt != LECLIP_F32;
-            if (res16) {
-#pragma unroll
-                for (int qu = 0; qu < 16; ++qu) {
-                    int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
-                    m = m < g.M ? m : g.M - 1;
-                    const int64_t rrow = e.rowmap_P ? m % e.rowmap_P + 1 : m;
-                    rpre[qu] = *(const i32x4*)((const char*)e.res + (rrow * e.ldr + n) * 2);
-                }
-            }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int h = q >> 2, i = q & 3;
@@ -290,51 +323,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                     if (m >= g.M) continue;
                     float vv[8];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) { vv[c] = v0[c] + b8[c]; vv[4 + c] = v1[c] + b8[4 + c]; }
-                    if (e.act == LECLIP_ACT_QUICKGELU) {
-                        // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): v_exp_f32 + v_rcp_f32
-#pragma unroll
-                        for (int c = 0; c < 8; ++c)
-                            vv[c] = vv[c] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * vv[c]));
-                    }
+                    for (int c = 0; c < 4; ++c) { vv[c] = v0[c]; vv[4 + c] = v1[c]; }
                     if ((g.dbg & 2) && vv[0] != 12345.678f) continue;
-                    int64_t orow = m, rrow = m;
-                    if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
-                    if (g.dbg & 8) orow = (m & 15) + 16 * (blockIdx.x & 255);   // diagnostic: cache-resident store footprint
-                    if (e.res) {
-                        if (e.res_dt == LECLIP_F32) {
-                            const float* rp = (const float*)e.res + rrow * e.ldr + n;
-                            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) { vv[c] += r0[c]; vv[4 + c] += r1[c]; }
-                        } else if (e.res_dt == LECLIP_BF16) {
-                            const bf16x8 r8 = __builtin_bit_cast(bf16x8, rpre[q * 2 + u]);
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
-                        } else {
-                            const f16x8 r8 = __builtin_bit_cast(f16x8, rpre[q * 2 + u]);
-#pragma unroll
-                            for (int c = 0; c < 8; ++c) vv[c] += (float)r8[c];
-                        }
-                    }
-                    if (e.out_dt == LECLIP_F32) {
-                        float* op = (float*)e.out + orow * e.ldy + n;
-                        f32x4 o0, o1;
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { o0[c] = vv[c]; o1[c] = vv[4 + c]; }
-                        *(f32x4*)op = o0;
-                        *(f32x4*)(op + 4) = o1;
-                    } else if (e.out_dt == LECLIP_BF16) {
-                        bf16x8 o8;
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)vv[c];
-                        *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
-                    } else {
-                        f16x8 o8;
-#pragma unroll
-                        for (int c = 0; c < 8; ++c) o8[c] = (f16_t)vv[c];
-                        *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
-                    }
+                    epi_chunk8<PF>(e, m, n, vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], lnpre[PF == 2 ? q * 2 + u : 0]);
                 }
             }
         } else if (p.acc[0][0][0][0] == 12345.678f) {
@@ -345,19 +336,28 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     }
 }
 
-template <typename T>
-int launch256(const Gemm256Args& a, hipStream_t s) {
+template <typename T, int PF>
+int launch256_pf(const Gemm256Args& a, int grid, hipStream_t s) {
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         attr_set = true;
     }
+    hipLaunchKernelGGL((gemm_tn_256x256x64_pp<T, PF>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    return leclip_check_launch("gemm_tn_256x256x64_pp");
+}
+
+template <typename T>
+int launch256(const Gemm256Args& a, hipStream_t s) {
     const int n_cu = leclip_gemm256_cus();
     static const int cap = [] { const char* e = getenv("LECLIP_GEMM_GRID"); return e ? atoi(e) : 0; }();   // test hook: force multi-tile loops
     const int limit = cap > 0 ? cap : n_cu;
     const int grid = a.tiles_total < limit ? a.tiles_total : limit;   // one persistent workgroup per CU (160 KiB LDS each)
-    hipLaunchKernelGGL(gemm_tn_256x256x64_pp<T>, dim3(grid), dim3(512), LDS_BYTES, s, a);
-    return leclip_check_launch("gemm_tn_256x256x64_pp");
+    const bool res16 = a.epi.res && a.epi.res_dt != LECLIP_F32;
+    if (!a.epi.res && !a.epi.ln_stats) return launch256_pf<T, 0>(a, grid, s);
+    if (res16 && !a.epi.ln_stats) return launch256_pf<T, 1>(a, grid, s);
+    if (a.epi.ln_stats && !a.epi.res) return launch256_pf<T, 2>(a, grid, s);
+    return launch256_pf<T, 3>(a, grid, s);   // fp32 residual (patch embedding) or residual + fused LayerNorm together
 }
 
 }  // namespace

@@ -78,7 +78,97 @@ struct EpiParams {
     int64_t ldr, ldy;
     int res_dt, out_dt, act;
     int rowmap_P;        // patch-embed mode: >0 => out row = m + m/P + 1, residual row = m % P + 1
+    // LayerNorm fused on the A side (A holds the un-normalised rows, W has gamma folded in):
+    //   v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]      with bias[n] = sum_k beta[k] W[n,k] + b[n]
+    const float* ln_stats;   // [M][2] = (mean, rstd) per row, or null
+    const float* ln_colsum;  // [N]    = sum_k (gamma[k] W[n,k])
+    // Row statistics of the OUTPUT for the next LayerNorm: (sum, sum of squares) of the rounded outputs per
+    // (row, 64-column block), written - not accumulated - so the result is deterministic and needs no zeroing.
+    float* stats_out;        // [M][stats_slots][2] or null
+    int stats_slots;
 };
+
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Shared 8-wide epilogue step of the 16-bit GEMM kernels: lane holds columns n..n+7 of output row m (8 lanes per
+// row: lanes with equal lane>>3).  b8 = bias chunk, s8 = ln_colsum chunk.
+// MODE (compile time): 0 = no residual, no fused LayerNorm; 1 = 16-bit residual prefetched in res_val; 2 = fused
+// LayerNorm with (mean, rstd) prefetched in ln_val; 3 = generic, everything decided and loaded at run time.  The
+// specialised modes keep every global LOAD out of the store loop (vmcnt retires loads and stores in order).
+template <int MODE>
+__device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n, float (&v)[8], const float (&b8)[8],
+                                           const float (&s8)[8], i32x4 res_val, f32x2 ln_val) {
+    constexpr bool have_res = MODE == 1, have_ln = MODE == 2;
+    // have_res / have_ln: the caller prefetched the 16-bit residual chunk / the row's (mean, rstd) into registers
+    // (passed by value: taking the address of a register array would push it to scratch memory)
+    if (MODE == 2 || (MODE == 3 && e.ln_stats)) {
+        const f32x2 st = have_ln ? ln_val : *(const f32x2*)(e.ln_stats + 2 * m);
+        const float mean = st[0], rstd = st[1];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, v[c] - mean * s8[c], b8[c]);
+    } else {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] += b8[c];
+    }
+    if (e.act == LECLIP_ACT_QUICKGELU) {
+        // x * sigmoid(1.702 x) = x / (1 + 2^(-1.702 log2(e) x)): v_exp_f32 + v_rcp_f32   (clip/model.py:202-204)
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = v[c] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[c]));
+    }
+    int64_t orow = m, rrow = m;
+    if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+    if (MODE == 1 || (MODE == 3 && e.res)) {
+        if (MODE == 3 && e.res_dt == LECLIP_F32) {
+            const float* rp = (const float*)e.res + rrow * e.ldr + n;
+            const f32x4 r0 = *(const f32x4*)rp, r1 = *(const f32x4*)(rp + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { v[c] += r0[c]; v[4 + c] += r1[c]; }
+        } else if (e.res_dt == LECLIP_BF16) {
+            const bf16x8 r8 = have_res ? __builtin_bit_cast(bf16x8, res_val) : *(const bf16x8*)((const bf16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+        } else {
+            const f16x8 r8 = have_res ? __builtin_bit_cast(f16x8, res_val) : *(const f16x8*)((const f16_t*)e.res + rrow * e.ldr + n);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
+        }
+    }
+    float s1 = 0.f, s2 = 0.f;
+    if (e.out_dt == LECLIP_F32) {
+        float* op = (float*)e.out + orow * e.ldy + n;
+        f32x4 o0, o1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { o0[c] = v[c]; o1[c] = v[4 + c]; }
+        *(f32x4*)op = o0;
+        *(f32x4*)(op + 4) = o1;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { s1 += v[c]; s2 = fmaf(v[c], v[c], s2); }
+    } else if (e.out_dt == LECLIP_BF16) {
+        bf16x8 o8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
+        *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float r = (float)o8[c]; s1 += r; s2 = fmaf(r, r, s2); }
+    } else {
+        f16x8 o8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
+        *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float r = (float)o8[c]; s1 += r; s2 = fmaf(r, r, s2); }
+    }
+    if (e.stats_out) {
+        // the 8 lanes of a row (consecutive lanes) hold its 64 columns of this wave: butterfly, lane 0 of the group writes
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if ((threadIdx.x & 7) == 0) {
+            f32x2 w;
+            w[0] = s1; w[1] = s2;
+            *(f32x2*)(e.stats_out + (orow * e.stats_slots + (n >> 6)) * 2) = w;
+        }
+    }
+}
 
 template <bool PRECISE>
 __device__ __forceinline__ float epi_apply(const EpiParams& p, int64_t m, int n, float v) {

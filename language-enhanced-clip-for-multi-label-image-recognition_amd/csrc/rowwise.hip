@@ -98,6 +98,47 @@ __device__ __forceinline__ float proj_column(const TP* __restrict__ p, const flo
     return acc;
 }
 
+// ------------------------------------------------------------------------------- row statistics for fused LayerNorm
+// (mean, rstd) per row, two-pass fp32 like layernorm_kernel (one wave per row).
+template <typename TI>
+__global__ __launch_bounds__(256) void row_stats_kernel(const TI* __restrict__ x, float* __restrict__ stats, int64_t rows, int dim,
+                                                        int64_t ldx, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const TI* xr = x + row * ldx;
+    const int nv = dim >> 8, tail = dim & 255;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv || (i == nv && lane * 4 < tail)) { v[i] = load4<TI>(xr + i * 256 + lane * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i)
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+        }
+    q = wave_sum(q);
+    if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(q / (float)dim + eps); }
+}
+
+// Reduce the per-(row, 64-column block) partial sums a GEMM epilogue wrote into (mean, rstd): fixed summation order.
+__global__ void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows, int slots,
+                                         int dim, float eps) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const f32x2* p = (const f32x2*)(partials + r * slots * 2);
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; s1 += t[0]; s2 += t[1]; }
+    const float mean = s1 / (float)dim;
+    const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
+    stats[2 * r] = mean;
+    stats[2 * r + 1] = rsqrtf(var + eps);
+}
+
 // ------------------------------------------------------------------------- gather + LayerNorm + projection
 // One workgroup per output row: the gathered row is normalised into LDS (fp32), then thread e accumulates
 // out[e] = sum_k xn[k] * proj[k][e] reading proj rows coalesced across threads.
@@ -394,5 +435,28 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
     EpiParams e;
     e.bias = nullptr; e.res = pos; e.out = X; e.ldr = width; e.ldy = width;
     e.res_dt = LECLIP_F32; e.out_dt = x_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = G * G;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
     return leclip_gemm_dispatch(workspace, Wp, B * G * G, width, Kp, Kp, Kp, e, w_dtype, s);
+}
+
+extern "C" int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, int dim, int64_t ldx, float eps, leclip_dtype x_dtype,
+                                    void* stream) {
+    if (!x || !stats || rows <= 0 || dim <= 0 || ldx < dim || !dtype_ok(x_dtype)) { leclip_set_error("row_stats: bad argument"); return LECLIP_E_INVALID; }
+    if (dim % 64 != 0 || dim > 256 * LN_MAXV || (ldx % 4) || ((uintptr_t)x & 7)) {
+        leclip_set_error("row_stats: dim=%d must be a multiple of 64 and <= %d, rows 8-byte aligned", dim, 256 * LN_MAXV); return LECLIP_E_UNSUPPORTED;
+    }
+    const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (x_dtype == LECLIP_F32) hipLaunchKernelGGL((row_stats_kernel<float>), grid, block, 0, s, (const float*)x, stats, rows, dim, ldx, eps);
+    else if (x_dtype == LECLIP_F16) hipLaunchKernelGGL((row_stats_kernel<f16_t>), grid, block, 0, s, (const f16_t*)x, stats, rows, dim, ldx, eps);
+    else hipLaunchKernelGGL((row_stats_kernel<bf16_t>), grid, block, 0, s, (const bf16_t*)x, stats, rows, dim, ldx, eps);
+    return leclip_check_launch("row_stats_kernel");
+}
+
+extern "C" int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
+                                            void* stream) {
+    if (!partials || !stats || rows <= 0 || slots <= 0 || dim <= 0) { leclip_set_error("ln_stats_finalize: bad argument"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, stats,
+                       rows, slots, dim, eps);
+    return leclip_check_launch("ln_stats_finalize_kernel");
 }

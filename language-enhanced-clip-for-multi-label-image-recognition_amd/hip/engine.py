@@ -24,12 +24,30 @@ from . import ops
 from ._capi import ACT_NONE, ACT_QUICKGELU
 
 
+import os
+
+# where the fused LayerNorm's row statistics come from: "epilogue" (partial sums written by the producing GEMM) or
+# "kernel" (a read-only pass over the residual stream)
+_LN_STATS_MODE = os.environ.get("LECLIP_LN_STATS", "epilogue")
+
+
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
 
 
 class _Block:
-    __slots__ = ("ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_pr", "b_pr")
+    __slots__ = ("ln1_w", "ln1_b", "w_qkv", "b_qkv", "w_o", "b_o", "ln2_w", "ln2_b", "w_fc", "b_fc", "w_pr", "b_pr",
+                 "wf_qkv", "cs_qkv", "cb_qkv", "wf_fc", "cs_fc", "cb_fc")
+
+
+def _fold_ln(w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype):
+    """LayerNorm folded into the consuming linear layer: W' = W * gamma (rounded once to the compute dtype),
+    colsum[n] = sum_k W'[n,k] (of the ROUNDED weights the MFMA will see), c[n] = sum_k beta[k] W[n,k] + b[n]."""
+    wq = w.detach().float()
+    wf = (wq * gamma.float()[None, :]).to(dtype).contiguous()
+    colsum = wf.float().sum(dim=1).contiguous()
+    cb = (wq.to(dtype).float() @ beta.float() + bias.float()).contiguous()
+    return wf, colsum, cb
 
 
 def pack_blocks(resblocks, dtype: torch.dtype, device):
@@ -47,6 +65,9 @@ def pack_blocks(resblocks, dtype: torch.dtype, device):
         p.b_fc = _f32(blk.mlp.c_fc.bias, device)
         p.w_pr = blk.mlp.c_proj.weight.detach().to(device=device, dtype=dtype).contiguous()
         p.b_pr = _f32(blk.mlp.c_proj.bias, device)
+        if dtype != torch.float32:
+            p.wf_qkv, p.cs_qkv, p.cb_qkv = _fold_ln(blk.attn.in_proj_weight.to(device), p.b_qkv, p.ln1_w, p.ln1_b, dtype)
+            p.wf_fc, p.cs_fc, p.cb_fc = _fold_ln(blk.mlp.c_fc.weight.to(device), p.b_fc, p.ln2_w, p.ln2_b, dtype)
         out.append(p)
     return out
 
@@ -59,11 +80,44 @@ class _Workspace:
         self.qkv = torch.empty((rows, 3 * d), dtype=dtype, device=device)
         self.ctx = torch.empty((rows, d), dtype=dtype, device=device)
         self.u = torch.empty((rows, 4 * d), dtype=dtype, device=device)
+        # fused-LayerNorm path: per-row (mean, rstd) and the epilogue's partial sums per 64-column block
+        self.stats = torch.empty((rows, 2), dtype=torch.float32, device=device)
+        self.partials = torch.empty((rows, d // 64, 2), dtype=torch.float32, device=device)
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
-               taps: Optional[dict] = None) -> torch.Tensor:
-    """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228)."""
+               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None) -> torch.Tensor:
+    """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
+
+    16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
+    epilogue emits per-row partial sums, a tiny kernel turns them into (mean, rstd), and the consuming GEMM multiplies
+    the raw residual rows by gamma-folded weights and normalises in its epilogue - LN(x) is never written to HBM nor
+    rounded to 16 bits.  The fp32 parity mode and the per-stage taps keep LayerNorm as its own kernel."""
+    d = x.shape[1]
+    if fuse_ln is None:
+        fuse_ln = x.dtype != torch.float32 and taps is None and d % 64 == 0
+    if fuse_ln:
+        ops.row_stats(x, out=ws.stats)
+        last = len(blocks) - 1
+        epilogue_stats = _LN_STATS_MODE == "epilogue"
+        for i, p in enumerate(blocks):
+            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_stats=ws.stats, ln_colsum=p.cs_qkv, out=ws.qkv)
+            ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
+            if epilogue_stats:
+                ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
+                ops.ln_stats_finalize(ws.partials, d, out=ws.stats)
+            else:
+                ops.gemm(ws.ctx, p.w_o, p.b_o, residual=x, out=x)
+                ops.row_stats(x, out=ws.stats)
+            ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_stats=ws.stats, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u)
+            if i < last and epilogue_stats:
+                ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
+                ops.ln_stats_finalize(ws.partials, d, out=ws.stats)
+            else:
+                ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
+                if i < last:
+                    ops.row_stats(x, out=ws.stats)
+        return x
     for i, p in enumerate(blocks):
         ops.layernorm(x, p.ln1_w, p.ln1_b, out=ws.h)
         ops.gemm(ws.h, p.w_qkv, p.b_qkv, out=ws.qkv)

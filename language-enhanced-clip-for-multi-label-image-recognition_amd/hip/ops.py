@@ -250,3 +250,54 @@ def eot_index(tokens: torch.Tensor):
     flat = torch.empty(n, dtype=torch.int64, device=tokens.device)
     _capi.check(_capi.load().leclip_eot_index_fwd(_ptr(tokens), _ptr(eot), _ptr(flat), n, t, _stream()), "eot_index")
     return eot, flat
+
+
+def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
+            ln_colsum: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+            stats_out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """GEMM with LayerNorm folded around it (see leclip_gemm_ln_fused_fwd): ``ln_stats`` [M,2] (mean, rstd) normalises
+    the A side algebraically, ``stats_out`` [M, N/64, 2] receives the output rows' partial (sum, sum of squares)."""
+    m, k, lda = _rows2d(a, "a")
+    n, kw, ldw = _rows2d(w, "w")
+    if k != kw or a.dtype != w.dtype:
+        raise ValueError(f"gemm_ln: a [.., {k}] {a.dtype} vs w [{n}, {kw}] {w.dtype}")
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (n,), dtype=out_dtype or a.dtype, device=a.device)
+    _, _, ldy = _rows2d(out, "out")
+    ldr, rdt = 0, _capi.F32
+    if residual is not None:
+        _, _, ldr = _rows2d(residual, "residual")
+        rdt = dtype_code(residual.dtype)
+    for name, t, shape in (("ln_stats", ln_stats, (m, 2)), ("ln_colsum", ln_colsum, (n,)), ("stats_out", stats_out, (m, n // 64, 2)),
+                           ("bias", bias, (n,))):
+        if t is not None:
+            _dev(t, name)
+            assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape, (name, tuple(t.shape), shape)
+    nbytes = (m * k + n * k) * a.element_size() + m * n * out.element_size() + (m * n * residual.element_size() if residual is not None else 0)
+    with _Timed("gemm", 2 * m * n * k, nbytes):
+        _capi.check(_capi.load().leclip_gemm_ln_fused_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(ln_stats), _ptr(ln_colsum), _ptr(residual),
+                                                          _ptr(out), _ptr(stats_out), m, n, k, lda, ldw, ldr, ldy, act,
+                                                          dtype_code(a.dtype), rdt, dtype_code(out.dtype), _stream()), "gemm_ln")
+    return out
+
+
+def ln_stats_finalize(partials: torch.Tensor, dim: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev(partials, "partials")
+    assert partials.dtype == torch.float32 and partials.dim() == 3 and partials.shape[2] == 2 and partials.is_contiguous()
+    rows, slots, _ = partials.shape
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
+    with _Timed("ln_stats", 0, partials.numel() * 4 + rows * 8):
+        _capi.check(_capi.load().leclip_ln_stats_finalize_fwd(_ptr(partials), _ptr(out), rows, slots, dim, eps, _stream()),
+                    "ln_stats_finalize")
+    return out
+
+
+def row_stats(x: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    rows, dim, ldx = _rows2d(x, "x")
+    if out is None:
+        out = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+    with _Timed("ln_stats", 0, rows * dim * x.element_size()):
+        _capi.check(_capi.load().leclip_row_stats_fwd(_ptr(x), _ptr(out), rows, dim, ldx, eps, dtype_code(x.dtype), _stream()), "row_stats")
+    return out

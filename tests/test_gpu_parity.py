@@ -93,6 +93,39 @@ def test_gemm_kernel_families(ops):
     np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=2e-3 * float(ref.abs().max()), rtol=0)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1576, 2304, 768), (49300, 256, 128)])
+def test_gemm_with_fused_layernorm(ops, dt, shape):
+    """leclip_gemm_ln_fused_fwd: LayerNorm folded around the GEMM (gamma into W, mean/rstd in the epilogue) against
+    LN -> linear in fp64, and the output-row statistics it emits for the next LayerNorm (128 and 256 kernel families)."""
+    from leclip_amd.hip import engine, ops as o
+    m, n, k = shape
+    x = (_rand((m, k), 41, 2.0) + 0.7).to(dt)
+    gamma, beta = _rand((k,), 42) * 0.1 + 1, _rand((k,), 43) * 0.1
+    w, b = _rand((n, k), 44, k ** -0.5), _rand((n,), 45) * 0.1
+    res = _rand((m, n), 46).to(dt)
+    xd = x.double()
+    mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
+    ref = ((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ w.double().t() + b.double()
+    ref_act = ref * torch.sigmoid(1.702 * ref) + res.double()
+    wf, cs, cb = engine._fold_ln(w.to(DEV), b.to(DEV), gamma.to(DEV), beta.to(DEV), dt)
+    stats = ops.row_stats(x.to(DEV))
+    np.testing.assert_allclose(stats[:, 0].cpu().numpy(), mu[:, 0].numpy(), atol=1e-5, rtol=1e-5)
+    np.testing.assert_allclose(stats[:, 1].cpu().numpy(), (1 / torch.sqrt(var + 1e-5))[:, 0].numpy(), rtol=1e-4)
+    y = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=stats, ln_colsum=cs, out_dtype=torch.float32)
+    scale = float(ref.abs().max())
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 0, 2.5e-3, 1.5e-2) * scale, rtol=0)
+    part = torch.empty((m, n // 64, 2), dtype=torch.float32, device=DEV)
+    y2 = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=stats, ln_colsum=cs, residual=res.to(DEV), act=o.ACT_QUICKGELU, stats_out=part)
+    np.testing.assert_allclose(y2.double().cpu().numpy(), ref_act.numpy(), atol=_tol(dt, 0, 4e-3, 2.5e-2) * float(ref_act.abs().max()), rtol=0)
+    st2 = ops.ln_stats_finalize(part, n)
+    yd = y2.double().cpu()
+    np.testing.assert_allclose(st2[:, 0].cpu().numpy(), yd.mean(1).numpy(), atol=2e-5 * float(yd.abs().max()), rtol=1e-4)
+    np.testing.assert_allclose(st2[:, 1].cpu().numpy(), (1 / torch.sqrt(yd.var(1, unbiased=False) + 1e-5)).numpy(), rtol=2e-4)
+    again = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=stats, ln_colsum=cs, residual=res.to(DEV), act=o.ACT_QUICKGELU, stats_out=part)
+    assert torch.equal(again, y2) and torch.equal(ops.ln_stats_finalize(part, n), st2)      # deterministic, no atomics
+
+
 def test_gemm_inplace_residual_and_errors(ops):
     from leclip_amd.hip._capi import HipKernelError
     a, w = _rand((300, 128), 8).bfloat16().to(DEV), _rand((128, 128), 9, 0.1).bfloat16().to(DEV)
