@@ -10,6 +10,7 @@
 // Workgroup ids are remapped so that each XCD (blocks b, b+8, ...) walks a contiguous run of tiles, N fastest:
 // the A row-panel of a tile row is re-read from that XCD's L2, not from HBM.
 #include "leclip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -209,7 +210,8 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
         const int64_t tile_rows = (M + 255) / 256, tn = N / 256, tiles = tile_rows * tn;
         const int64_t rounds = tiles / n_cu, rem = tiles % n_cu;
         const int64_t full_rows = rounds * n_cu / tn;
-        if (rounds >= 1 && rem > 0 && 2 * rem <= n_cu && !epi.rowmap_P && full_rows > 0 && full_rows * 256 < M) {
+        static const int split_min_k = [] { const char* e = getenv("LECLIP_GEMM_SPLIT_MINK"); return e ? atoi(e) : 0; }();
+        if (rounds >= 1 && rem > 0 && 2 * rem <= n_cu && !epi.rowmap_P && full_rows > 0 && full_rows * 256 < M && K >= split_min_k) {
             const int64_t M1 = full_rows * 256;
             int rc = leclip_gemm256_launch(A, W, M1, N, K, lda, ldw, epi, ab_dtype, s);
             if (rc) return rc;

@@ -40,14 +40,17 @@ class _Block:
                  "wf_qkv", "cs_qkv", "cb_qkv", "wf_fc", "cs_fc", "cb_fc")
 
 
-def _fold_ln(w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype):
+def _fold_ln(w: torch.Tensor, bias: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, dtype: torch.dtype, device=None):
     """LayerNorm folded into the consuming linear layer: W' = W * gamma (rounded once to the compute dtype),
-    colsum[n] = sum_k W'[n,k] (of the ROUNDED weights the MFMA will see), c[n] = sum_k beta[k] W[n,k] + b[n]."""
-    wq = w.detach().float()
-    wf = (wq * gamma.float()[None, :]).to(dtype).contiguous()
-    colsum = wf.float().sum(dim=1).contiguous()
-    cb = (wq.to(dtype).float() @ beta.float() + bias.float()).contiguous()
-    return wf, colsum, cb
+    colsum[n] = sum_k W'[n,k] (of the ROUNDED weights the MFMA will see), c[n] = sum_k beta[k] W[n,k] + b[n].
+    One-off host-side packing arithmetic (fp64 on the CPU); nothing here runs per forward."""
+    device = device if device is not None else w.device
+    wq = w.detach().cpu().double()
+    g, bt, b0 = gamma.detach().cpu().double(), beta.detach().cpu().double(), bias.detach().cpu().double()
+    wf = (wq * g[None, :]).float().to(dtype)
+    colsum = wf.double().sum(dim=1).float()
+    cb = (wq.float().to(dtype).double() @ bt + b0).float()
+    return wf.contiguous().to(device), colsum.contiguous().to(device), cb.contiguous().to(device)
 
 
 def pack_blocks(resblocks, dtype: torch.dtype, device):
@@ -66,8 +69,8 @@ def pack_blocks(resblocks, dtype: torch.dtype, device):
         p.w_pr = blk.mlp.c_proj.weight.detach().to(device=device, dtype=dtype).contiguous()
         p.b_pr = _f32(blk.mlp.c_proj.bias, device)
         if dtype != torch.float32:
-            p.wf_qkv, p.cs_qkv, p.cb_qkv = _fold_ln(blk.attn.in_proj_weight.to(device), p.b_qkv, p.ln1_w, p.ln1_b, dtype)
-            p.wf_fc, p.cs_fc, p.cb_fc = _fold_ln(blk.mlp.c_fc.weight.to(device), p.b_fc, p.ln2_w, p.ln2_b, dtype)
+            p.wf_qkv, p.cs_qkv, p.cb_qkv = _fold_ln(blk.attn.in_proj_weight, p.b_qkv, p.ln1_w, p.ln1_b, dtype, device)
+            p.wf_fc, p.cs_fc, p.cb_fc = _fold_ln(blk.mlp.c_fc.weight, p.b_fc, p.ln2_w, p.ln2_b, dtype, device)
         out.append(p)
     return out
 
@@ -160,6 +163,9 @@ class VisionEngine:
         self.ln_pre_w, self.ln_pre_b = _f32(visual.ln_pre.weight, device), _f32(visual.ln_pre.bias, device)
         self.ln_post_w, self.ln_post_b = _f32(visual.ln_post.weight, device), _f32(visual.ln_post.bias, device)
         self.proj = visual.proj.detach().to(device=device, dtype=dtype).contiguous()
+        e = self.proj.shape[1]
+        ok = (e % 128 == 0 and self.width % 64 == 0) if dtype != torch.float32 else (e % 64 == 0 and self.width % 32 == 0)
+        self.proj_t = self.proj.t().contiguous() if ok else None   # [E, d] nn.Linear layout for the projection GEMM
         self.blocks = pack_blocks(visual.transformer.resblocks, dtype, device)
         self._ws: Dict[int, tuple] = {}
 
@@ -189,7 +195,12 @@ class VisionEngine:
         if taps is not None:
             taps["ln_pre"] = x.float().clone()
         run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps)
-        # ln_post on the class token only, then @ proj (clip/model.py:271-274); fp32 features
+        # ln_post on the class token only, then @ proj (clip/model.py:271-274); fp32 features.  The class rows sit at a
+        # fixed stride (T*d), so LayerNorm reads them in place (ldx = T*d) and the projection is a small MFMA GEMM.
+        if self.proj_t is not None:
+            cls = x.view(batch, self.tokens * self.width)[:, :self.width]
+            h = ops.layernorm(cls, self.ln_post_w, self.ln_post_b)
+            return ops.gemm(h, self.proj_t, out_dtype=torch.float32)
         return ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)
 
 

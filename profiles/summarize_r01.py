@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn gpurun_out/prof_r01_final/* (rocprofv3 csv) into the committed summaries under profiles/:
+r01_kernel_stats.csv (per-kernel time), r01_pmc_summary.json (per-launch HBM traffic + MFMA utilisation of the GEMM)."""
+import collections, csv, glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "gpurun_out", "prof_r01_final")
+
+def counters(sub):
+    f = glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv"))[0]
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(f)):
+        per[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    return per
+
+def by_kernel(per, match):
+    agg = collections.defaultdict(list)
+    for (name, _), c in per.items():
+        if match in name:
+            for k, v in c.items():
+                agg[k].append(v)
+    return {k: sum(v) / len(v) for k, v in agg.items()}, max((len(v) for v in agg.values()), default=0)
+
+stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
+rows = list(csv.DictReader(open(stats)))
+with open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv"), "w") as f:
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage"])
+    for r in rows:
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]])
+out = {"command": "rocprofv3 --kernel-trace [--stats | --pmc ...] -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline",
+       "note": "FETCH_SIZE/WRITE_SIZE are KB of L2<->fabric traffic (Infinity-Cache hits included); per MI355X_MICROARCH.md "
+               "FETCH_SIZE reads exactly half of a wide coalesced stream on gfx950, so read bytes = 2*FETCH_SIZE*1024."}
+fetch, nf = by_kernel(counters("pmc_fetch"), "gemm_tn_256x256x64_pp")
+write, _ = by_kernel(counters("pmc_write"), "gemm_tn_256x256x64_pp")
+sq, _ = by_kernel(counters("pmc_sq"), "gemm_tn_256x256x64_pp")
+grbm, _ = by_kernel(counters("pmc_grbm"), "gemm_tn_256x256x64_pp")
+rd = 2 * fetch.get("FETCH_SIZE", 0) * 1024
+wr = write.get("WRITE_SIZE", 0) * 1024
+out["gemm_tn_256x256x64_pp"] = {
+    "dispatches_averaged": nf, "FETCH_SIZE_KB": fetch.get("FETCH_SIZE"), "WRITE_SIZE_KB": write.get("WRITE_SIZE"),
+    "read_bytes_corrected": rd, "write_bytes": wr,
+    "l2_hit_rate": write.get("TCC_HIT_sum", 0) / max(write.get("TCC_HIT_sum", 0) + write.get("TCC_MISS_sum", 0), 1),
+    "SQ": sq, "GRBM_GUI_ACTIVE": grbm.get("GRBM_GUI_ACTIVE"),
+    "mfma_busy_frac_of_simd_cycles": sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(grbm.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)}
+out["gemm_hbm_bytes_per_launch"] = rd + wr
+for name in ("attn_heads_kernel", "gemm_tn_128x128x64"):
+    f2, _ = by_kernel(counters("pmc_fetch"), name)
+    w2, _ = by_kernel(counters("pmc_write"), name)
+    out[name] = {"read_bytes_corrected": 2 * f2.get("FETCH_SIZE", 0) * 1024, "write_bytes": w2.get("WRITE_SIZE", 0) * 1024}
+json.dump(out, open(os.path.join(ROOT, "profiles", "r01_pmc_summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
