@@ -47,22 +47,33 @@ def all_gather_rows(local: torch.Tensor, counts=None) -> torch.Tensor:
     world = dist.get_world_size()
     local = local.contiguous()
     if counts is None:
-        out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(out, local)
-        return out
+        return _gather_flat(local, world)
     width = max(counts)
     padded = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
-    out = torch.empty((world * width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, padded)
+    out = _gather_flat(padded, world)
     return torch.cat([out[r * width:r * width + counts[r]] for r in range(world)], dim=0)
+
+
+def _gather_flat(block: torch.Tensor, world: int) -> torch.Tensor:
+    """Equal-size blocks -> one [world * n, ...] tensor in rank order.  RCCL: a single all_gather_into_tensor on one flat
+    buffer; backends without that primitive for this device (gloo with device tensors) use the list form."""
+    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    try:
+        dist.all_gather_into_tensor(out, block)
+    except (RuntimeError, NotImplementedError):
+        parts = [torch.empty_like(block) for _ in range(world)]
+        dist.all_gather(parts, block)
+        out = torch.cat(parts, dim=0)
+    return out
 
 
 class ShardedScorer:
     """Scores a global batch: each rank runs ``score_fn`` on its contiguous shard, logits are all-gathered."""
 
-    def __init__(self, score_fn):
+    def __init__(self, score_fn, n_out: int = 80):
         self.score_fn = score_fn
+        self.n_out = n_out          # logit columns (80 COCO labels); only used when a rank's shard is empty
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.world = dist.get_world_size() if dist.is_initialized() else 1
 
@@ -72,7 +83,11 @@ class ShardedScorer:
 
     def score_local(self, local_images: torch.Tensor, n_global: Optional[int] = None) -> torch.Tensor:
         """``local_images`` is already this rank's shard; returns the gathered [n_global, C] logits on every rank."""
+        if local_images.shape[0] == 0:   # ragged split with more ranks than images: this rank contributes no rows
+            counts = [shard_bounds(n_global, r, self.world)[1] - shard_bounds(n_global, r, self.world)[0] for r in range(self.world)]
+            return all_gather_rows(torch.zeros((0, self.n_out), dtype=torch.float32, device=local_images.device), counts)
         logits = self.score_fn(local_images)
+        self.n_out = logits.shape[1]
         if self.world == 1:
             return logits
         if n_global is None or n_global == self.world * local_images.shape[0]:

@@ -29,7 +29,7 @@ def _worker(rank, world, port, n_global, out_q):
     assert (r, w) == (rank, world)
     g = torch.Generator().manual_seed(5)
     images = torch.randn(n_global, 3, 4, 4, generator=g)
-    sc = parallel.ShardedScorer(_score)
+    sc = parallel.ShardedScorer(_score, n_out=5)
     lo, hi = parallel.shard_bounds(n_global, rank, world)
     gathered = sc.score_local(images[lo:hi].contiguous(), n_global)
     gathered2 = sc.score_global(images)

@@ -399,3 +399,71 @@ def test_train_caption_eval_entry_point(ops):
                               "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)", "TRAINER.Caption.PREC", "fp32",
                               "DATALOADER.TEST.BATCH_SIZE", "16"])
     assert 0.0 < out["mAP"] <= 100.0
+
+
+def test_module_surface_extras(ops, golden_dir):
+    """Pieces of the reference surface not on the headline path: TextEncoder(if_sequence=True) (CDD.py:94-96),
+    Transformer.forward in the reference's LND layout, the LayerNorm module, encode_text == TextEncoder on embeddings."""
+    from leclip_amd.trainers import TextEncoder
+    from oracle import clip_oracle as co
+    sd = synth.make_state_dict(synth.TINY, seed=1, dist="cond")
+    m = _build(synth.TINY, 1, "cond", torch.float32)
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    toks = torch.from_numpy(t["tokens_photo"][:4])
+    te = TextEncoder(m)
+    emb = sd["token_embedding.weight"][toks]
+    seq = te(emb.to(DEV), toks.to(DEV), if_embedding=True, if_sequence=True)
+    ref_seq = co.text_encoder(emb, toks, sd, if_sequence=True)
+    np.testing.assert_allclose(seq.cpu().numpy(), ref_seq.numpy(), atol=2e-4, rtol=1e-4)
+    pooled = te(emb.to(DEV), toks.to(DEV))
+    np.testing.assert_allclose(pooled.cpu().numpy(), m.encode_text(toks.to(DEV)).cpu().numpy(), atol=1e-5, rtol=0)
+    np.testing.assert_allclose(pooled.cpu().numpy(), co.encode_text(toks, sd).numpy(), atol=2e-4, rtol=1e-4)
+    ids = te(toks.to(DEV), None, if_embedding=False)
+    assert torch.equal(ids, pooled)
+    # Transformer.forward: LND in, LND out (model.py:231-239), causal text stack
+    x = (emb + sd["positional_embedding"]).permute(1, 0, 2).contiguous()
+    y = m.transformer(x.to(DEV)).permute(1, 0, 2).cpu()
+    xr = emb + sd["positional_embedding"]
+    for i in range(synth.TINY.transformer_layers):
+        xr = co.residual_block(xr, sd, f"transformer.resblocks.{i}.", 2, co.causal_mask(77))
+    np.testing.assert_allclose(y.numpy(), xr.numpy(), atol=3e-4, rtol=3e-4)
+    ln = m.ln_final(xr.to(DEV))
+    np.testing.assert_allclose(ln.cpu().numpy(), co.layer_norm(xr, sd["ln_final.weight"], sd["ln_final.bias"]).numpy(), atol=2e-5, rtol=0)
+
+
+def _rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from leclip_amd import parallel
+    from leclip_amd.clip import build_model
+    parallel.init_from_env(backend="gloo")       # 2 ranks share the one GPU of the test box: gloo carries the device tensors
+    m = build_model(synth.make_state_dict(synth.TINY, seed=1)).float().to(DEV)
+    toks = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "tokens_coco80.npz"))["tokens_photo"][:8]).to(DEV)
+    img = torch.from_numpy(synth.make_images(7, 32, seed=3)).to(DEV)        # ragged: 4 + 3
+    sc = parallel.ShardedScorer(lambda x: m(x, toks)[0])
+    got = sc.score_global(img)
+    ref = m(img, toks)[0]
+    q.put((rank, bool(torch.allclose(got, ref, atol=1e-5)), tuple(got.shape)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_scoring_two_ranks_on_device(ops):
+    """parallel.ShardedScorer with the real HIP scorer on device tensors, world size 2 (both ranks on cuda:0, gloo
+    transport): per-rank shards + all-gather of logits == unsharded logits."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == [(0, True, (7, 8)), (1, True, (7, 8))]
