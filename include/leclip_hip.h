@@ -134,6 +134,21 @@ int leclip_add_pos_fwd(const float* in, const float* pos, void* x, int64_t n, in
  * row n*T + argmax used by leclip_gather_ln_proj_fwd. */
 int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream);
 
+/* ---- backward of the text tower w.r.t. its ACTIVATIONS (prompt tuning: only the context vectors are trainable, reference
+ * trainers/Caption_distill_double.py:762-765, 789-897).  dX of a linear layer is leclip_gemm_bias_act_res_fwd on a
+ * transposed weight copy; the three kernels below cover the rest. */
+/* dx = d LayerNorm(x)/dx applied to dy (gamma frozen), optionally + add (the residual branch's upstream gradient).
+ * All tensors [rows, dim] contiguous in `dtype`; statistics recomputed in fp32. */
+int leclip_layernorm_bwd(const void* dy, const void* x, const float* gamma, const void* add, void* dx, int64_t rows, int dim,
+                         float eps, leclip_dtype dtype, void* stream);
+/* QuickGELU as its own kernel for the training forward (the pre-activation must be kept) and its derivative:
+ * out = pre * sigmoid(1.702 pre);   dpre = du * sigmoid(1.702 pre) * (1 + 1.702 pre (1 - sigmoid(1.702 pre))).  n % 4 == 0. */
+int leclip_quickgelu_fwd(const void* pre, void* out, int64_t n, leclip_dtype dtype, void* stream);
+int leclip_quickgelu_bwd(const void* pre, const void* du, void* dpre, int64_t n, leclip_dtype dtype, void* stream);
+/* Gradient of leclip_attention_fwd w.r.t. the packed qkv (probabilities recomputed); T <= 104, head_dim 64. */
+int leclip_attention_bwd(const void* qkv, const void* dout, void* dqkv, int64_t B, int T, int heads, int head_dim, int64_t ld_qkv,
+                         int64_t ld_out, leclip_mask mask, float scale, leclip_dtype dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,128 @@
+"""Autograd bridges for prompt tuning: gradients flow from the text features back to the learnable context vectors
+through the frozen text tower (reference trainers/Caption_distill_double.py:762-765, 789-897).
+
+Only ACTIVATION gradients are formed (every CLIP weight is frozen), so the backward of each linear layer is the
+forward TN GEMM kernel on a transposed weight copy; LayerNorm, QuickGELU and attention have their own backward
+kernels (``csrc/backward.hip``).  ``torch.autograd.Function`` is the seam: above it ordinary autograd (loss, SGD on
+``ctx``), below it only ``leclip_*`` kernels.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class _BwdWeights:
+    """Transposed copies of one block's weights ([in, out] with `out` contiguous), packed on first backward."""
+    __slots__ = ("qkv_t", "o_t", "fc_t", "pr_t")
+
+    def __init__(self, p):
+        self.qkv_t = p.w_qkv.t().contiguous()   # [d, 3d]
+        self.o_t = p.w_o.t().contiguous()       # [d, d]
+        self.fc_t = p.w_fc.t().contiguous()     # [d, 4d]
+        self.pr_t = p.w_pr.t().contiguous()     # [4d, d]
+
+
+def _bwd_weights(engine):
+    if getattr(engine, "_bwd", None) is None:
+        engine._bwd = [_BwdWeights(p) for p in engine.blocks]
+    return engine._bwd
+
+
+class TextTowerFunction(torch.autograd.Function):
+    """features = TextEncoder(prompts) (CDD.py:82-101) with a hand-written backward w.r.t. ``prompts``."""
+
+    @staticmethod
+    def forward(ctx, prompts: torch.Tensor, engine, tokenized_prompts: torch.Tensor):
+        n, t, d = prompts.shape
+        heads = engine.heads
+        x = ops.add_pos(prompts.detach().to(dtype=torch.float32), engine.pos, engine.dtype).view(n * t, d)
+        saved = []
+        for p in engine.blocks:
+            h1 = ops.layernorm(x, p.ln1_w, p.ln1_b)
+            qkv = ops.gemm(h1, p.w_qkv, p.b_qkv)
+            att = ops.attention(qkv, n, t, heads, True)
+            x_mid = ops.gemm(att, p.w_o, p.b_o, residual=x)
+            h2 = ops.layernorm(x_mid, p.ln2_w, p.ln2_b)
+            pre = ops.gemm(h2, p.w_fc, p.b_fc)
+            u = ops.quickgelu(pre)
+            x_out = ops.gemm(u, p.w_pr, p.b_pr, residual=x_mid)
+            saved.append((x, qkv, x_mid, pre))
+            x = x_out
+        _, flat = ops.eot_index(tokenized_prompts.to(prompts.device).contiguous())
+        feats = ops.gather_ln_proj(x, flat, engine.ln_w, engine.ln_b, engine.proj)
+        ctx.engine, ctx.saved, ctx.x_last, ctx.flat, ctx.shape = engine, saved, x, flat, (n, t, d)
+        return feats
+
+    @staticmethod
+    def backward(ctx, dfeat: torch.Tensor):
+        engine, (n, t, d) = ctx.engine, ctx.shape
+        dt = engine.dtype
+        bw = _bwd_weights(engine)
+        # features = LN(x[eot]) @ proj: d(LN out) = dfeat @ proj^T  (proj [d, E] is already the [N'=d, K'=E] layout)
+        dln = ops.gemm(dfeat.to(dt).contiguous(), engine.proj)
+        rows = ctx.x_last[ctx.flat].contiguous()
+        drows = ops.layernorm_bwd(dln, rows, engine.ln_w)
+        dx = torch.zeros((n * t, d), dtype=dt, device=dfeat.device)
+        dx.index_copy_(0, ctx.flat, drows)
+        for p, w, (x_in, qkv, x_mid, pre) in zip(reversed(engine.blocks), reversed(bw), reversed(ctx.saved)):
+            du = ops.gemm(dx, w.pr_t)                                   # through c_proj
+            dpre = ops.quickgelu_bwd(pre, du)
+            dh2 = ops.gemm(dpre, w.fc_t)                                # through c_fc
+            dxm = ops.layernorm_bwd(dh2, x_mid, p.ln2_w, add=dx)        # ln_2 + the residual branch
+            dctx = ops.gemm(dxm, w.o_t)                                 # through out_proj
+            dqkv = ops.attention_bwd(qkv, dctx, n, t, engine.heads, True)
+            dh1 = ops.gemm(dqkv, w.qkv_t)                               # through in_proj
+            dx = ops.layernorm_bwd(dh1, x_in, p.ln1_w, add=dxm)         # ln_1 + the residual branch
+        return dx.view(n, t, d).float(), None, None
+
+
+class PromptAssembleFunction(torch.autograd.Function):
+    """prompts = cat(prefix, ctx, suffix) (CDD.py:206-225); backward: the context slice, summed over classes for a
+    generic (class-shared) context."""
+
+    @staticmethod
+    def forward(ctx, ctx_vectors: torch.Tensor, prefix: torch.Tensor, suffix: torch.Tensor):
+        ctx.per_class = ctx_vectors.dim() == 3
+        ctx.n_ctx = ctx_vectors.shape[-2]
+        return ops.prompt_assemble(prefix, ctx_vectors.detach().float().contiguous(), suffix, None, torch.float32)
+
+    @staticmethod
+    def backward(ctx, dprompts: torch.Tensor):
+        g = dprompts[:, 1:1 + ctx.n_ctx, :]
+        return (g.contiguous() if ctx.per_class else g.sum(dim=0)), None, None
+
+
+class CosineLogitsFunction(torch.autograd.Function):
+    """logits = scale * normalize(img) @ normalize(txt).T (CDD.py:330-335) with the gradient w.r.t. the text features
+    (image features come from frozen encoders: no gradient).  The [C,B]x[B,E] contraction of the backward runs on the
+    exact-fp32 MFMA GEMM; the normalisation Jacobian is a few elementwise ops on a [C, E] matrix."""
+
+    @staticmethod
+    def forward(ctx, img: torch.Tensor, txt: torch.Tensor, scale: float):
+        img = img.detach().float().contiguous()
+        txt_d = txt.detach().float().contiguous()
+        ctx.save_for_backward(img, txt_d)
+        ctx.scale = float(scale)
+        return ops.l2norm_logits(img, txt_d, scale)
+
+    @staticmethod
+    def backward(ctx, dlogits: torch.Tensor):
+        img, txt = ctx.saved_tensors
+        b, e = img.shape
+        inorm = img / img.norm(dim=-1, keepdim=True)
+        tn = txt.norm(dim=-1, keepdim=True)
+        that = txt / tn
+        pad = (-b) % 32                       # the fp32 GEMM wants K % 32 == 0
+        dl_t = dlogits.float().t().contiguous()            # [C, B]
+        in_t = inorm.t().contiguous()                      # [E, B]  = W' with N' = E, K' = B
+        if pad:
+            dl_t = torch.nn.functional.pad(dl_t, (0, pad))
+            in_t = torch.nn.functional.pad(in_t, (0, pad))
+        if e % 64 == 0:
+            dthat = ops.gemm(dl_t.contiguous(), in_t.contiguous()) * ctx.scale      # [C, E]
+        else:                                   # odd embed dims (tiny test models): tiny host-side product
+            dthat = (dl_t @ in_t.t()) * ctx.scale
+        dtxt = (dthat - that * (dthat * that).sum(dim=-1, keepdim=True)) / tn
+        return None, dtxt, None

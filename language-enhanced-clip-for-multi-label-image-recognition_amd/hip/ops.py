@@ -301,3 +301,45 @@ def row_stats(x: torch.Tensor, eps: float = 1e-5, out: Optional[torch.Tensor] = 
     with _Timed("ln_stats", 0, rows * dim * x.element_size()):
         _capi.check(_capi.load().leclip_row_stats_fwd(_ptr(x), _ptr(out), rows, dim, ldx, eps, dtype_code(x.dtype), _stream()), "row_stats")
     return out
+
+
+# ------------------------------------------------------------------------------------------- backward (prompt tuning)
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, gamma: torch.Tensor, add: Optional[torch.Tensor] = None,
+                  eps: float = 1e-5) -> torch.Tensor:
+    """dx of LayerNorm (gamma frozen) applied to dy, plus ``add`` (upstream gradient of the residual branch)."""
+    _dev(dy, "dy"), _dev(x, "x")
+    assert dy.shape == x.shape and dy.dtype == x.dtype and dy.is_contiguous() and x.is_contiguous()
+    assert add is None or (add.shape == x.shape and add.dtype == x.dtype and add.is_contiguous())
+    rows, dim = x.numel() // x.shape[-1], x.shape[-1]
+    dx = torch.empty_like(x)
+    _capi.check(_capi.load().leclip_layernorm_bwd(_ptr(dy), _ptr(x), _ptr(_dev(gamma, "gamma")), _ptr(add), _ptr(dx), rows, dim, eps,
+                                                  dtype_code(x.dtype), _stream()), "layernorm_bwd")
+    return dx
+
+
+def quickgelu(pre: torch.Tensor) -> torch.Tensor:
+    _dev(pre, "pre")
+    assert pre.is_contiguous()
+    out = torch.empty_like(pre)
+    _capi.check(_capi.load().leclip_quickgelu_fwd(_ptr(pre), _ptr(out), pre.numel(), dtype_code(pre.dtype), _stream()), "quickgelu_fwd")
+    return out
+
+
+def quickgelu_bwd(pre: torch.Tensor, du: torch.Tensor) -> torch.Tensor:
+    _dev(pre, "pre"), _dev(du, "du")
+    assert pre.shape == du.shape and pre.dtype == du.dtype and pre.is_contiguous() and du.is_contiguous()
+    out = torch.empty_like(pre)
+    _capi.check(_capi.load().leclip_quickgelu_bwd(_ptr(pre), _ptr(du), _ptr(out), pre.numel(), dtype_code(pre.dtype), _stream()),
+                "quickgelu_bwd")
+    return out
+
+
+def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, batch: int, tokens: int, heads: int, causal: bool) -> torch.Tensor:
+    rows, width3, ld = _rows2d(qkv, "qkv")
+    d = heads * 64
+    assert rows == batch * tokens and width3 == 3 * d and dout.shape == (rows, d) and dout.dtype == qkv.dtype and dout.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    _capi.check(_capi.load().leclip_attention_bwd(_ptr(qkv), _ptr(_dev(dout, "dout")), _ptr(dqkv), batch, tokens, heads, 64, ld, d,
+                                                  MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype), _stream()),
+                "attention_bwd")
+    return dqkv

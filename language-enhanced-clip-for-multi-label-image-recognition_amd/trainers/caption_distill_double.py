@@ -76,6 +76,9 @@ class TextEncoder(nn.Module):
         eng = self._clip[0].text_engine(prompts.device)
         if not if_embedding:
             return eng.encode_tokens(prompts, if_sequence=if_sequence)
+        if torch.is_grad_enabled() and prompts.requires_grad and not if_sequence:
+            from ..hip.autograd import TextTowerFunction     # prompt tuning: gradient w.r.t. the prompt embeddings
+            return TextTowerFunction.apply(prompts, eng, tokenized_prompts)
         return eng.encode_prompts(prompts, tokenized_prompts, if_sequence=if_sequence)
 
 
@@ -150,6 +153,9 @@ class PromptLearner(nn.Module):
         suffix_neg = suffix if neg_prompt_wcls else self.token_suffix_nocls.float().contiguous()
 
         def cat(ctx, suf):
+            if torch.is_grad_enabled() and ctx.requires_grad:
+                from ..hip.autograd import PromptAssembleFunction
+                return PromptAssembleFunction.apply(ctx, prefix, suf)
             return ops.prompt_assemble(prefix, ctx.detach().float().contiguous(), suf, None, torch.float32)
 
         return (cat(self.ctx, suffix), cat(self.ctx_double, suffix_neg), cat(self.ctx_evidence, suffix_neg),
@@ -182,12 +188,19 @@ class CustomCLIP(nn.Module):
 
     def forward(self, image=None, captions=None, if_test: bool = False):
         from ..hip import ops
-        if if_test:
-            image_features = self.image_encoder(image)
-        else:
-            image_features = self.text_encoder(captions, None, if_embedding=False, if_sequence=False)
-        text_features = self.class_text_features()
         logit_scale = 4.0  # reference :333-334 (not logit_scale.exp())
+        with torch.no_grad():   # both "image" encoders are frozen (reference :762-765)
+            if if_test or image is not None:
+                image_features = self.image_encoder(image)
+            else:
+                image_features = self.text_encoder(captions, None, if_embedding=False, if_sequence=False)
+        if torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad and self.training:
+            from ..hip.autograd import CosineLogitsFunction
+            prompts = self.prompt_learner()[0]
+            text_features = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))
+            self._text_cache = None
+            return CosineLogitsFunction.apply(image_features, text_features, logit_scale), None, None, None
+        text_features = self.class_text_features()
         logits = ops.l2norm_logits(image_features, text_features, logit_scale)
         return logits, None, None, None
 
@@ -250,8 +263,59 @@ class Caption_distill_double:
     def parse_batch_train(self, batch):
         return batch["img"].to(self.device), batch["label"].to(self.device)
 
+    def build_optim(self):
+        """SGD on the prompt learner only + cosine schedule with a constant-LR warm-up epoch (dassl/optim/optimizer.py:13-137,
+        lr_scheduler.py:10-154 with the shipped OPTIM keys)."""
+        o = self.cfg.OPTIM
+        model = self._models[self.get_model_names()[0]]
+        params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
+        self.optim = torch.optim.SGD(params, lr=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY)
+        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, T_max=max(int(o.MAX_EPOCH), 1))
+        self._base_lr = o.LR
+        if o.WARMUP_EPOCH > 0 and o.WARMUP_TYPE == "constant":
+            for g in self.optim.param_groups:
+                g["lr"] = o.WARMUP_CONS_LR
+        return self.optim
+
+    def update_lr(self):
+        o = self.cfg.OPTIM
+        self.epoch += 1
+        if self.epoch == o.WARMUP_EPOCH and o.WARMUP_TYPE == "constant":
+            for g in self.optim.param_groups:
+                g["lr"] = self._base_lr
+        elif self.epoch > o.WARMUP_EPOCH:
+            self.sched.step()
+
     def forward_backward(self, batch):
-        raise NotImplementedError("prompt-tuning step: text-tower backward kernels are the next scope row (N1)")
+        """One prompt-tuning step (reference :789-897, fp32 branch).  ``batch["img"]`` is either tokenised captions
+        [B,77] int64 - the reference's texts-as-images feed, ``model(None, captions)`` - or images [B,3,R,R]
+        (CoOp-style tuning on the frozen image tower, BASELINE config 3).  Loss: ``ranking_loss(scale_=1, margin_=1)``
+        for LOSSFUNC == "double_ranking" (:806-808), BCE-with-logits for "bce" (trainers/utils.py:21-23)."""
+        from .utils import norm_logits_BCEloss, ranking_loss
+        if getattr(self, "optim", None) is None:
+            self.build_optim()
+        name = self.get_model_names()[0]
+        model = self._models[name]
+        model.train()
+        inp, label = self.parse_batch_train(batch)
+        if inp.dtype in (torch.int64, torch.int32):
+            output = model(None, inp.long())[0]
+        else:
+            output = model(inp, None)[0]
+        lf = self.cfg.TRAIN.LOSSFUNC
+        if lf == "double_ranking":
+            loss = ranking_loss(output, label, scale_=1.0, margin_=1)
+        elif lf == "bce":
+            loss = norm_logits_BCEloss(output, label.float())
+        else:
+            raise NotImplementedError(f"loss function {lf} not implemented")
+        if not torch.isfinite(loss):
+            raise FloatingPointError("Loss is infinite or NaN!")   # dassl/engine/trainer.py:224-226
+        self.optim.zero_grad()
+        loss.backward()
+        self.optim.step()
+        model._text_cache = None
+        return {f"loss_{lf}": loss.item(), "loss": loss.item()}
 
     @torch.no_grad()
     def test(self, split=None, mode="test"):
