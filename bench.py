@@ -46,7 +46,12 @@ def main():
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--mode", default="score", choices=["score", "tune"],
+                    help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
+                         "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
     args = ap.parse_args()
+    if args.mode == "tune":
+        return tune(args)
 
     import numpy as np
     import torch
@@ -149,6 +154,39 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def tune(args):
+    """Secondary measurement (not the headline metric): prompt-tuning steps on image batches, BASELINE configs[2]."""
+    import torch
+    from leclip_amd import parallel, synth
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+
+    rank, world, _ = parallel.init_from_env()
+    assert world == 1, "tune mode is a single-GPU measurement in this round"
+    B = args.batch if args.batch != 256 else 512
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", args.arch, "MODEL.BACKBONE.PATH", "synthetic:0:cond", "TRAINER.Caption.PREC",
+                         args.dtype if args.dtype != "fp16" else "fp16", "TRAIN.LOSSFUNC", "bce", "OPTIM.WARMUP_EPOCH", "0"])
+    tr = build_trainer(cfg)
+    arch = synth.ARCHS[args.arch]
+    images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234)).to(tr.device)
+    labels = torch.from_numpy((synth.uniform(3, "tune.labels", (B, 80), 0, 1) < 0.04).astype("float32")).to(tr.device)
+    batch = {"img": images, "label": labels}
+    for _ in range(args.warmup):
+        out = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.forward_backward(batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "images/sec (prompt-tuning step, ViT-B/16 frozen image tower + text tower fwd/bwd w.r.t. 16 ctx, B=512)",
+                      "value": B * args.steps / dt, "unit": "img/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "dtype": args.dtype, "data": "synthetic",
+                      "config": {"workload": f"BASELINE configs[2]: {args.arch}, 16 learnable context tokens, B={B}, BCE, SGD"},
+                      "last_loss": out["loss"]}))
 
 
 def _pmc_traffic():

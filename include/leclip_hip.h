@@ -134,6 +134,16 @@ int leclip_add_pos_fwd(const float* in, const float* pos, void* x, int64_t n, in
  * row n*T + argmax used by leclip_gather_ln_proj_fwd. */
 int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream);
 
+/* ---- score post-processing of the reference's test loop
+ * Sliding-window aggregation, trainers/Caption_distill_double.py:654-660: window_logits [B, W, C] are the scores of the W
+ * crops of each image; alpha = max_w, beta = min_w, s_ag = alpha > threshold ? alpha : beta, out = weight * s_ag + global
+ * (reference: threshold 0.3, weight 1.4).  All fp32. */
+int leclip_window_aggregate_fwd(const float* global_logits, const float* window_logits, float* out, int64_t B, int W, int C,
+                                float threshold, float weight, void* stream);
+/* Co-occurrence modulation, Caption_distill_double.py:614-618 (adjust_predictions) with the matrix of :632-634:
+ * out = p + weight * (p @ Mn), Mn [C, C] = row-normalised(adj / nums[:, None]) built on the host (reference weight 0.5). */
+int leclip_cooccurrence_adjust_fwd(const float* p, const float* Mn, float* out, int64_t B, int C, float weight, void* stream);
+
 /* ---- backward of the text tower w.r.t. its ACTIVATIONS (prompt tuning: only the context vectors are trainable, reference
  * trainers/Caption_distill_double.py:762-765, 789-897).  dX of a linear layer is leclip_gemm_bias_act_res_fwd on a
  * transposed weight copy; the three kernels below cover the rest. */

@@ -195,6 +195,33 @@ __global__ __launch_bounds__(256) void l2norm_logits_kernel(const float* __restr
     logits[idx] = (scale * it) / (sqrtf(ii) * sqrtf(tt));
 }
 
+// ------------------------------------------------------------------- score post-processing
+// Sliding-window aggregation (trainers/Caption_distill_double.py:654-660): per image and class, alpha = max over windows,
+// beta = min over windows, s_ag = alpha if alpha > thr else beta, out = w_ag * s_ag + global.   One thread per (b, c).
+__global__ void window_aggregate_kernel(const float* __restrict__ glob, const float* __restrict__ blocks, float* __restrict__ out,
+                                        int64_t B, int W, int C, float thr, float w_ag) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    const float* p = blocks + b * W * C + c;
+    float mx = p[0], mn = p[0];
+    for (int w = 1; w < W; ++w) { const float v = p[(int64_t)w * C]; mx = fmaxf(mx, v); mn = fminf(mn, v); }
+    out[i] = w_ag * (mx > thr ? mx : mn) + glob[i];
+}
+
+// Co-occurrence modulation (Caption_distill_double.py:614-618, 632-636): out = p + weight * (p @ Mn), Mn [C, C] row-normalised.
+__global__ void cooccurrence_adjust_kernel(const float* __restrict__ p, const float* __restrict__ Mn, float* __restrict__ out,
+                                           int64_t B, int C, float weight) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int64_t b = i / C;
+    const int c = (int)(i - b * C);
+    float acc = 0.f;
+    for (int k = 0; k < C; ++k) acc = fmaf(p[b * C + k], Mn[(int64_t)k * C + c], acc);
+    out[i] = p[i] + weight * acc;
+}
+
 // ------------------------------------------------------------------------------ embeddings / prompt assembly
 __global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
                                     const float* __restrict__ pos, void* __restrict__ x, int64_t n_rows, int T, int dim,
@@ -459,4 +486,19 @@ extern "C" int leclip_ln_stats_finalize_fwd(const float* partials, float* stats,
     hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, stats,
                        rows, slots, dim, eps);
     return leclip_check_launch("ln_stats_finalize_kernel");
+}
+
+extern "C" int leclip_window_aggregate_fwd(const float* global_logits, const float* window_logits, float* out, int64_t B, int W, int C,
+                                           float threshold, float weight, void* stream) {
+    if (!global_logits || !window_logits || !out || B <= 0 || W <= 0 || C <= 0) { leclip_set_error("window_aggregate: bad argument"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(window_aggregate_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, global_logits,
+                       window_logits, out, B, W, C, threshold, weight);
+    return leclip_check_launch("window_aggregate_kernel");
+}
+
+extern "C" int leclip_cooccurrence_adjust_fwd(const float* p, const float* Mn, float* out, int64_t B, int C, float weight, void* stream) {
+    if (!p || !Mn || !out || B <= 0 || C <= 0 || p == out) { leclip_set_error("cooccurrence_adjust: bad argument (out must not alias p)"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(cooccurrence_adjust_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p, Mn, out, B, C,
+                       weight);
+    return leclip_check_launch("cooccurrence_adjust_kernel");
 }

@@ -53,6 +53,8 @@ SIGNATURES = {
     "leclip_prompt_assemble_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                            c_int, c_int, c_int, c_void_p]),
     "leclip_add_pos_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "leclip_window_aggregate_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_float, c_void_p]),
+    "leclip_cooccurrence_adjust_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "leclip_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_float, c_int, c_void_p]),
     "leclip_quickgelu_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "leclip_quickgelu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),

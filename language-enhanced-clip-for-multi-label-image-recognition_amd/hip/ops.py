@@ -343,3 +343,35 @@ def attention_bwd(qkv: torch.Tensor, dout: torch.Tensor, batch: int, tokens: int
                                                   MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype), _stream()),
                 "attention_bwd")
     return dqkv
+
+
+# ------------------------------------------------------------------------------------- score post-processing (N2 / N3)
+def window_aggregate(global_logits: torch.Tensor, window_logits: torch.Tensor, threshold: float = 0.3, weight: float = 1.4) -> torch.Tensor:
+    """out = weight * s_ag + global with s_ag = max over windows if it exceeds ``threshold`` else min (CDD.py:654-660)."""
+    _dev(global_logits, "global_logits"), _dev(window_logits, "window_logits")
+    g, w = global_logits.float().contiguous(), window_logits.float().contiguous()
+    b, c = g.shape
+    assert w.dim() == 3 and w.shape[0] == b and w.shape[2] == c
+    out = torch.empty_like(g)
+    _capi.check(_capi.load().leclip_window_aggregate_fwd(_ptr(g), _ptr(w), _ptr(out), b, w.shape[1], c, threshold, weight, _stream()),
+                "window_aggregate")
+    return out
+
+
+def cooccurrence_matrix(adj, nums) -> torch.Tensor:
+    """Row-normalised conditional co-occurrence matrix of CDD.py:632-634 from ``freq_stats.pkl``'s {'adj', 'nums'} (host side)."""
+    import numpy as np
+    p = np.asarray(adj, dtype=np.float64) / np.asarray(nums, dtype=np.float64)[:, None]
+    p = p / p.sum(-1)[:, None]
+    return torch.from_numpy(p.astype(np.float32))
+
+
+def cooccurrence_adjust(p: torch.Tensor, mn: torch.Tensor, weight: float = 0.5) -> torch.Tensor:
+    """p + weight * (p @ Mn) (adjust_predictions, CDD.py:614-618)."""
+    _dev(p, "p"), _dev(mn, "Mn")
+    p, mn = p.float().contiguous(), mn.float().contiguous()
+    b, c = p.shape
+    assert mn.shape == (c, c)
+    out = torch.empty_like(p)
+    _capi.check(_capi.load().leclip_cooccurrence_adjust_fwd(_ptr(p), _ptr(mn), _ptr(out), b, c, weight, _stream()), "cooccurrence_adjust")
+    return out

@@ -43,3 +43,19 @@ def norm_logits_bce(pred: np.ndarray, targets: np.ndarray) -> float:
     x = np.asarray(pred, dtype=np.float64)
     t = np.asarray(targets, dtype=np.float64)
     return float(np.mean(np.maximum(x, 0.0) - x * t + np.log1p(np.exp(-np.abs(x)))))
+
+
+def window_aggregate(global_logits: np.ndarray, window_logits: np.ndarray, threshold: float = 0.3, weight: float = 1.4) -> np.ndarray:
+    """trainers/Caption_distill_double.py:654-660: alpha = max over windows, beta = min over windows,
+    gamma = alpha > threshold, s_ag = gamma*alpha + (1-gamma)*beta, final = 1.4*s_ag + global.  (Restated from the
+    inline code of ``test()``; that method is not callable in isolation, so this function is pinned by formula only.)"""
+    alpha, beta = window_logits.max(axis=1), window_logits.min(axis=1)
+    gamma = (alpha > threshold).astype(window_logits.dtype)
+    return weight * (gamma * alpha + (1 - gamma) * beta) + global_logits
+
+
+def cooccurrence_adjust(p: np.ndarray, adj: np.ndarray, nums: np.ndarray, weight: float = 0.5) -> np.ndarray:
+    """Caption_distill_double.py:614-618 + 632-636: M = adj / nums[:, None]; M /= M.sum(-1)[:, None]; p + weight * (p @ M)."""
+    m = adj / nums[:, None]
+    m = m / m.sum(-1)[:, None]
+    return p + weight * (p @ m)

@@ -467,3 +467,20 @@ def test_sharded_scoring_two_ranks_on_device(ops):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == [(0, True, (7, 8)), (1, True, (7, 8))]
+
+
+def test_score_postprocessing(ops):
+    """Sliding-window aggregation and co-occurrence modulation against the numpy restatement."""
+    from oracle import metrics_oracle as mo
+    rng = np.random.RandomState(5)
+    glob = rng.randn(37, 80).astype(np.float32) * 0.3
+    blocks = rng.randn(37, 116, 80).astype(np.float32) * 0.3      # 116 crops per image as in the reference's comment
+    blocks[:, :, 3] -= 2.0                                         # a class that never crosses the threshold -> min branch
+    got = ops.window_aggregate(torch.from_numpy(glob).to(DEV), torch.from_numpy(blocks).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, mo.window_aggregate(glob, blocks), atol=1e-6, rtol=0)
+    assert (blocks[:, :, 3].max(1) <= 0.3).all()
+    adj = rng.randint(0, 50, size=(80, 80)).astype(np.float64) + 1
+    nums = adj.sum(1) + 10
+    mn = ops.cooccurrence_matrix(adj, nums)
+    got = ops.cooccurrence_adjust(torch.from_numpy(glob).to(DEV), mn.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, mo.cooccurrence_adjust(glob.astype(np.float64), adj, nums), atol=2e-6, rtol=0)
