@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams (kernel tails of one "
+                    "half overlap the other half's kernels)")
     ap.add_argument("--mode", default="score", choices=["score", "tune"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
@@ -84,7 +86,23 @@ def main():
 
     B = args.batch
     images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(dev)
-    scorer = parallel.ShardedScorer(lambda x: cc(x, if_test=True)[0])
+    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
+    parts = list(images.chunk(args.streams)) if streams else None
+
+    def score_fn(x):
+        if streams is None:
+            return cc(x, if_test=True)[0]
+        cur = torch.cuda.current_stream()
+        outs = []
+        for st, part in zip(streams, parts):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                outs.append(cc(part, if_test=True)[0])
+        for st in streams:
+            cur.wait_stream(st)
+        return torch.cat(outs, dim=0)
+
+    scorer = parallel.ShardedScorer(score_fn)
 
     def step():
         return scorer.score_local(images)

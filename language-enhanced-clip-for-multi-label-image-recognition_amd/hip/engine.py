@@ -170,16 +170,20 @@ class VisionEngine:
         self._ws: Dict[int, tuple] = {}
 
     def _workspace(self, batch: int):
-        if batch not in self._ws:
-            self._ws.clear()  # one live batch shape: HBM is large but bench shapes are few
+        # one workspace per (batch size, HIP stream): forwards issued on different streams (batch halves overlapping each
+        # other's kernel tails) must not share activation buffers
+        key = (batch, torch.cuda.current_stream(self.device).cuda_stream)
+        if key not in self._ws:
+            if len(self._ws) >= 4:
+                self._ws.clear()
             rows = batch * self.tokens
-            self._ws[batch] = (
+            self._ws[key] = (
                 _Workspace(rows, self.width, self.dtype, self.device),
                 torch.empty((rows, self.width), dtype=self.dtype, device=self.device),
                 ops.patch_embed_workspace(batch, self.resolution, self.patch, self.dtype, self.device),
                 (torch.arange(batch, device=self.device, dtype=torch.int64) * self.tokens).contiguous(),
             )
-        return self._ws[batch]
+        return self._ws[key]
 
     def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.resolution or image.shape[3] != self.resolution:
