@@ -54,7 +54,9 @@ __device__ __forceinline__ void stage_tile(const T* __restrict__ g, int64_t ld, 
     }
 }
 
-template <typename T>
+// PF: what the epilogue prefetches into registers before its first store (same meaning as in gemm_mfma256.hip):
+// 0 nothing, 1 the 16-bit residual, 2 the fused-LayerNorm row statistics, 3 generic (loads inside the store loop).
+template <typename T, int PF>
 __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
     typedef typename VecOf<T>::v8 v8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -122,14 +124,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
     // every wave-instruction covers 8 full 128-byte output lines.  Wave-local: no workgroup barrier.
     const EpiParams& e = g.epi;
     float* st = (float*)(smem + wave * EPI_WAVE_BYTES);
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + j * 32 + fr] = acc[i][j][r];
-
     const int crow = lane >> 3, ccol = (lane & 7) * 8;
     const int n = n0 + wc * 64 + ccol;
     float b8[8];
@@ -148,6 +142,49 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) { s8[c] = t0[c]; s8[4 + c] = t1[c]; }
     }
+    // Every global load of the epilogue is issued here, ahead of the first store, waited for once and laundered
+    // through empty asm so hipcc does not guard each use with vmcnt(0): loads and stores retire in order, a load
+    // inside the store loop would wait for all earlier stores of the wave.
+    i32x4 rpre[PF == 1 ? 8 : 1];
+    f32x2 lnpre[PF == 2 ? 8 : 1];
+    if constexpr (PF == 1) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int64_t m = m0 + wr * 64 + it * 8 + crow;
+            m = m < g.M ? m : g.M - 1;
+            const int64_t rrow = e.rowmap_P ? m % e.rowmap_P + 1 : m;
+            rpre[it] = *(const i32x4*)((const char*)e.res + (rrow * e.ldr + n) * 2);
+        }
+    }
+    if constexpr (PF == 2) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            int64_t m = m0 + wr * 64 + it * 8 + crow;
+            m = m < g.M ? m : g.M - 1;
+            lnpre[it] = *(const f32x2*)(e.ln_stats + 2 * m);
+        }
+    }
+    // park the accumulators while those loads are in flight
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + j * 32 + fr] = acc[i][j][r];
+    if constexpr (PF != 3) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { asm volatile("" : "+v"(b8[c])); asm volatile("" : "+v"(s8[c])); }
+        if constexpr (PF == 1) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(rpre[it]));
+        }
+        if constexpr (PF == 2) {
+#pragma unroll
+            for (int it = 0; it < 8; ++it) asm volatile("" : "+v"(lnpre[it]));
+        }
+    }
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
         const int row = it * 8 + crow;
@@ -157,19 +194,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
         float v[8];
 #pragma unroll
         for (int c = 0; c < 4; ++c) { v[c] = v0[c]; v[4 + c] = v1[c]; }
-        epi_chunk8<3>(e, m, n, v, b8, s8, i32x4{0, 0, 0, 0}, f32x2{0.f, 0.f});
+        epi_chunk8<PF>(e, m, n, v, b8, s8, rpre[PF == 1 ? it : 0], lnpre[PF == 2 ? it : 0]);
     }
+}
+
+template <typename T, int PF>
+int launch_mfma_pf(const GemmArgs& a, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_128x128x64<T, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((gemm_tn_128x128x64<T, PF>), dim3(a.tiles_total), dim3(256), LDS_BYTES, s, a);
+    return leclip_check_launch("gemm_tn_128x128x64");
 }
 
 template <typename T>
 int launch_mfma(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_128x128x64<T>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(gemm_tn_128x128x64<T>, dim3(a.tiles_total), dim3(256), LDS_BYTES, s, a);
-    return leclip_check_launch("gemm_tn_128x128x64");
+    const bool res16 = a.epi.res && a.epi.res_dt != LECLIP_F32;
+    if (!a.epi.res && !a.epi.ln_stats) return launch_mfma_pf<T, 0>(a, s);
+    if (res16 && !a.epi.ln_stats) return launch_mfma_pf<T, 1>(a, s);
+    if (a.epi.ln_stats && !a.epi.res) return launch_mfma_pf<T, 2>(a, s);
+    return launch_mfma_pf<T, 3>(a, s);
 }
 
 }  // namespace
