@@ -51,6 +51,8 @@ struct Gemm256Args {
     EpiParams epi;
     int tiles_n, tiles_total;
     int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
+    unsigned long long* stamps;   // diagnostic build (-DLECLIP_GEMM_STAMPS) only: s_memtime stamps, [workgroup][16 tiles][8]
+    int strict_wait;   // 1: never relax the first K-tile's vmcnt waits past the previous epilogue's stores (A/B timing)
     int dbg;   // diagnostic: 1 skip epilogue, 2 skip global stores, 4 skip K-loop (LECLIP_GEMM_DEBUG; timing experiments only)
 };
 
@@ -61,6 +63,18 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 }
 
 #define PIN() __builtin_amdgcn_sched_barrier(0)
+
+// In-kernel timeline (diagnostic library build only; the shipped kernel contains no stamp): wave 0 / lane 0 of every
+// workgroup records the shader clock at five points of each tile.
+#ifdef LECLIP_GEMM_STAMPS
+#define STAMP(k)                                                                                              \
+    do {                                                                                                      \
+        if (g.stamps && wave == 0 && lane == 0 && tile_it < 16)                                               \
+            g.stamps[((size_t)blockIdx.x * 16 + tile_it) * 8 + (k)] = __builtin_amdgcn_s_memtime();          \
+    } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
@@ -115,7 +129,12 @@ struct PP {
     }
 
     // One K-tile.  V = 0 steady state (tiles t+1 and t+2 exist), 1 = second to last (only t+1 exists), 2 = last.
-    template <int V>
+    // X: vector-memory operations that are YOUNGER than the next tile's prologue DMA but are not K-loop DMA - the
+    // output stores of the previous tile's epilogue.  vmcnt retires in order, so the waits of a tile's first K-tile
+    // (which only need prologue DMA, older than those stores) may leave X more operations outstanding: the stores get
+    // a whole K-tile to be acknowledged instead of stalling the first MFMA cluster.  Chosen at run time (t == 0) by a
+    // scalar branch around the two s_waitcnt forms: a peeled copy of the K-tile costs registers (hoisted addresses).
+    template <int V, int X = 0>
     __device__ __forceinline__ void ktile(int t) {
         const int s = t & 1;
         const int k1 = (t + 1) * TK, k2 = (t + 2) * TK;
@@ -128,7 +147,10 @@ struct PP {
         // ---- phase 1: (k0, r1)
         read_a(s, 0, 1);
         if (V <= 1) stage_a(1 - s, 1, k1 + 32);
-        if (V <= 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // k1 slots of tile t landed (this wave's pieces)
+        if (V <= 1) {   // k1 slots of tile t landed (this wave's pieces)
+            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        }
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PIN();
         compute(1);
@@ -141,8 +163,13 @@ struct PP {
         // ---- phase 3: (k1, r1)
         read_a(s, 1, 1);
         if (V == 0) stage_a(s, 0, k2);
-        if (V == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // k0 slots of tile t+1 landed
-        else if (V == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (V == 0) {   // k0 slots of tile t+1 landed
+            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (V == 1) {
+            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + X) : "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
         PIN();
         compute(1);
     }
@@ -258,14 +285,20 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     // De-synchronise the CUs: all workgroups start together and would otherwise run K-loops and epilogues in
     // lockstep, leaving HBM idle during the K-loops and saturated (MFMA idle) during the store bursts.
     if (g.desync) {
-        const int phi = (blockIdx.x >> 3) & 3;
-        for (int i = 0; i < phi * g.desync; ++i) __builtin_amdgcn_s_sleep(127);
+        const int groups = g.desync >> 8 ? g.desync >> 8 : 4;            // desync = groups * 256 + step (step in ~512-cycle units)
+        const int phi = (blockIdx.x >> 3) % groups;
+        for (int i = 0; i < phi * (g.desync & 255); ++i) __builtin_amdgcn_s_sleep(8);
     }
     int v = blockIdx.x;
     int64_t m0;
     int n0;
     tile_origin(v, m0, n0);
     prologue(m0, n0);
+    // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 16 partial-sum pairs)
+    constexpr int EPI_STORES = CFG >= 0 ? 16 * (1 + ((CFG >> 1) & 1)) : 0;
+    int tile_it = 0;
+    (void)tile_it;
+    bool drain = CFG >= 0;   // false: the previous tile ended with exactly EPI_STORES stores after this tile's prologue DMA
     while (true) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -275,26 +308,37 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                 for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) p.acc[h][i][j][r] = 0.f;
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");   // tile 0, k0 slots (at least) have landed
+        // Tile 0's k0 slots (at least) have landed.  The first K-tile of every tile is the <., EPI_STORES> variant: its
+        // waits leave EPI_STORES younger operations outstanding, which is exact after an unchecked specialised epilogue;
+        // in every other case (`drain`: first tile of the workgroup, edge tile, diagnostic paths) everything is drained
+        // here instead, so nothing that variant could under-wait for is still in flight.
+        if (drain) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + EPI_STORES) : "memory");
         PIN();
         __builtin_amdgcn_s_barrier();
         PIN();
         if (wm == 1) __builtin_amdgcn_s_barrier();   // stagger: the second M-half runs one barrier behind
         PIN();
 
+        STAMP(0);
         int t = 0;
         if (g.dbg & 4) t = nk - 2 > 0 ? nk - 2 : 0;
-        for (; t + 2 < nk; ++t) p.template ktile<0>(t);
-        p.template ktile<1>(t);
+        for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t);
+        p.template ktile<1, EPI_STORES>(t);
 
         p.template ktile<2>(t + 1);
+        STAMP(1);
 
         // Epilogue operands (bias, LayerNorm column sums, and - for the whole tile, 16 chunks per lane - the 16-bit
         // residual or the fused LayerNorm's (mean, rstd)) are requested right after the last MFMA
         // cluster: their latency overlaps the barriers that close the K-loop.
         const int64_t em0 = m0;
         const int en0 = n0;
-        const int crow = lane >> 3, ccol = (lane & 7) * 8;
+        int lane_e = lane;   // laundered: everything derived from it is recomputed per tile instead of being hoisted out of
+        // the persistent loop as per-lane invariants that do not fit beside the K-loop's registers.  (Not for the residual
+        // prefetch: its 16 row addresses are cheaper as hoisted base + scalar offsets than recomputed all at once.)
+        if constexpr (PF != 1) asm volatile("" : "+v"(lane_e));
+        const int crow = lane_e >> 3, ccol = (lane_e & 7) * 8;
         const int n = en0 + wn * 64 + ccol;
         float b8[8], s8[8];
 #pragma unroll
@@ -310,7 +354,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             for (int c = 0; c < 4; ++c) { s8[c] = t0[c]; s8[4 + c] = t1[c]; }
         }
         i32x4 rpre[PF == 1 ? 16 : 1];
-        f32x2 lnpre[PF == 2 ? 16 : 1];
+        // fused LayerNorm: the 8 lanes that share an output row need the same (mean, rstd), so each of them keeps only
+        // two of the wave's 16 row slots - lane (crow, c) holds rows c*16 + crow and c*16 + 8 + crow - and a pass fetches
+        // its pair from lane c = q of its 8-lane group with ds_bpermute (4 VGPRs instead of 32)
+        f32x2 lnpre[PF == 2 ? 2 : 1];
         if constexpr (PF == 1) {
 #pragma unroll
             for (int qu = 0; qu < 16; ++qu) {
@@ -322,10 +369,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         }
         if constexpr (PF == 2) {
 #pragma unroll
-            for (int qu = 0; qu < 16; ++qu) {
-                int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
+            for (int u = 0; u < 2; ++u) {
+                int64_t m = em0 + wm * 128 + (lane_e & 7) * 16 + u * 8 + crow;
                 m = m < g.M ? m : g.M - 1;
-                lnpre[qu] = *(const f32x2*)(e.ln_stats + 2 * m);
+                lnpre[u] = *(const f32x2*)(e.ln_stats + 2 * m);
             }
         }
         PIN();
@@ -348,12 +395,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         }
         if constexpr (PF == 2) {
 #pragma unroll
-            for (int qu = 0; qu < 16; ++qu) asm volatile("" : "+v"(lnpre[qu]));
+            for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(lnpre[u]));
         }
+        STAMP(2);
         if (more) {   // next tile's first K-tiles: their HBM/L2 latency overlaps this tile's epilogue
             tile_origin(vn, m0, n0);
             prologue(m0, n0);
         }
+        STAMP(3);
 
         // ---- epilogue: 8 passes of 16 rows.  The wave parks a 16x64 fp32 strip in its own 4 KiB staging region
         // (column block XOR-swizzled by (row>>2)&1 so the column-per-lane ds_write_b32 do not conflict) and re-reads
@@ -363,11 +412,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             // q+1 is written before strip q is read back, so the LDS write->read round trip of one strip hides behind
             // the other's arithmetic and stores).  The 64 KiB come from the epilogue region plus the k1 slots of
             // stage 1, which the next tile's prologue does not touch.
+            drain = true;
             if (!(g.dbg & 1)) {
                 constexpr int ACT = CFG & 1, STATS = (CFG >> 1) & 1;
                 float* st = (float*)(smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES));
-                const int wsw = ((lane >> 4) & 1) << 4;
-                const int wr_off = 4 * (lane >> 4) * 64 + (lane & 15);
+                const int wsw = ((lane_e >> 4) & 1) << 4;
+                const int wr_off = 4 * (lane_e >> 4) * 64 + (lane_e & 15);
                 auto park = [&](int q) {
                     float* sq = st + (q & 1) * (EPI_WAVE_BYTES / 4) + wr_off;
 #pragma unroll
@@ -394,13 +444,21 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #pragma unroll
                             for (int c = 0; c < 4; ++c) { vv[c] = v0[c]; vv[4 + c] = v1[c]; }
                             if (decltype(nostore)::value && vv[0] != 12345.678f) continue;
-                            epi_fast_chunk<T, PF, ACT, STATS>(vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], lnpre[PF == 2 ? q * 2 + u : 0],
+                            f32x2 ln = lnpre[0];
+                            if constexpr (PF == 2) {
+                                const int src = ((lane_e & ~7) | q) << 2;   // byte address of the source lane
+                                // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
+                                const float mean_l = lnpre[u][0], rstd_l = lnpre[u][1];
+                                ln[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mean_l)));
+                                ln[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rstd_l)));
+                            }
+                            epi_fast_chunk<T, PF, ACT, STATS>(vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], ln,
                                                               optr + (int64_t)roff * e.ldy, STATS ? sptr + (int64_t)roff * e.stats_slots * 2 : nullptr);
                         }
                     }
                 };
                 if (g.dbg & 2) passes(BoolC<true>{}, BoolC<true>{});
-                else if (em0 + TM <= g.M) passes(BoolC<false>{}, BoolC<false>{});
+                else if (em0 + TM <= g.M) { passes(BoolC<false>{}, BoolC<false>{}); drain = g.strict_wait != 0; }
                 else passes(BoolC<true>{}, BoolC<false>{});
             } else if (p.acc[0][0][0][0] == 12345.678f) {
                 ((float*)e.out)[0] = 1.f;
@@ -428,12 +486,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { vv[c] = v0[c]; vv[4 + c] = v1[c]; }
                     if ((g.dbg & 2) && vv[0] != 12345.678f) continue;
-                    epi_chunk8<PF>(e, m, n, vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], lnpre[PF == 2 ? q * 2 + u : 0]);
+                    epi_chunk8<PF>(e, m, n, vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], lnpre[0]);   // (generic code is only instantiated for PF == 3)
                 }
             }
         } else if (p.acc[0][0][0][0] == 12345.678f) {
             ((float*)e.out)[0] = 1.f;
         }
+        STAMP(4);
+        ++tile_it;
         if (!more) break;
         v = vn;
     }
@@ -472,6 +532,10 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 
 }  // namespace
 
+static unsigned long long* g_stamps = nullptr;
+// diagnostic hook (kernel_check --stamps, library built with -DLECLIP_GEMM_STAMPS): device buffer for the in-kernel timeline
+extern "C" void leclip_gemm256_set_stamps(unsigned long long* device_buf) { g_stamps = device_buf; }
+
 int leclip_gemm256_cus() {
     static int n_cu = 0;
     if (!n_cu) {
@@ -505,5 +569,8 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.dbg = dbg;
     static const int desync = [] { const char* e = getenv("LECLIP_GEMM_DESYNC"); return e ? atoi(e) : 0; }();
     a.desync = desync;
+    a.stamps = g_stamps;
+    static const int strict_wait = [] { const char* e = getenv("LECLIP_GEMM_STRICT_WAIT"); return e ? atoi(e) : 0; }();
+    a.strict_wait = strict_wait;
     return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
 }

@@ -176,9 +176,73 @@ static void bench() {
     }
 }
 
+
+// Diagnostic: in-kernel timeline of the 256x256 GEMM (needs the library built with -DLECLIP_GEMM_STAMPS: make stamps).
+extern "C" void leclip_gemm256_set_stamps(unsigned long long* device_buf) __attribute__((weak));
+static void stamps() {
+    if (!leclip_gemm256_set_stamps) { printf("library built without the stamp hook\n"); return; }
+    const int64_t M = 256 * 197;
+    struct S { int N, K, act; bool res; const char* name; } shapes[] = {
+        {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
+    const int dt = LECLIP_BF16;
+    const size_t n_st = 256 * 16 * 8;
+    Buf dS(n_st * 8);
+    for (auto& s : shapes) {
+        auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
+        auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
+        Buf dA(Ap.size()), dW(Wp.size()), dB(s.N * 4), dR(Rp.size()), dY((size_t)M * s.N * 2);
+        dA.up(Ap.data()); dW.up(Wp.data()); dB.up(Bv.data()); dR.up(Rp.data());
+        auto run = [&] {
+            leclip_gemm_bias_act_res_fwd(dA.d, dW.d, (float*)dB.d, s.res ? dR.d : nullptr, dY.d, M, s.N, s.K, s.K, s.K, s.N, s.N,
+                                         (leclip_act)s.act, (leclip_dtype)dt, (leclip_dtype)dt, (leclip_dtype)dt, nullptr);
+        };
+        leclip_gemm256_set_stamps(nullptr);
+        for (int i = 0; i < 200; ++i) run();   // settle the clock
+        HIPCHK(hipMemset(dS.d, 0, n_st * 8));
+        leclip_gemm256_set_stamps((unsigned long long*)dS.d);
+        run();
+        HIPCHK(hipDeviceSynchronize());
+        leclip_gemm256_set_stamps(nullptr);
+        std::vector<unsigned long long> st(n_st);
+        dS.down(st.data());
+        // per tile index: mean over workgroups of the five segment lengths (cycles)
+        printf("stamps %-10s N=%d K=%d   (cycles, mean over workgroups; wave 0)\n", s.name, s.N, s.K);
+        printf("  tile   n_wg   kloop  close+operands  prologue-issue  passes  wait-at-next-top   tile-total\n");
+        for (int it = 0; it < 16; ++it) {
+            double seg[6] = {0, 0, 0, 0, 0, 0};
+            int n = 0, n_next = 0;
+            for (int wg = 0; wg < 256; ++wg) {
+                const unsigned long long* t = &st[((size_t)wg * 16 + it) * 8];
+                if (!t[0] || !t[4]) continue;
+                ++n;
+                seg[0] += (double)(t[1] - t[0]); seg[1] += (double)(t[2] - t[1]); seg[2] += (double)(t[3] - t[2]); seg[3] += (double)(t[4] - t[3]);
+                if (it + 1 < 16) {
+                    const unsigned long long* u = &st[((size_t)wg * 16 + it + 1) * 8];
+                    if (u[0]) { seg[4] += (double)(u[0] - t[4]); seg[5] += (double)(u[0] - t[0]); ++n_next; }
+                }
+            }
+            if (!n) break;
+            printf("  %4d  %5d  %6.0f  %14.0f  %14.0f  %6.0f  %16.0f  %11.0f\n", it, n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n,
+                   n_next ? seg[4] / n_next : 0.0, n_next ? seg[5] / n_next : 0.0);
+        }
+        // skew between workgroups at the first and the last stamp
+        unsigned long long lo0 = ~0ull, hi0 = 0, lo4 = ~0ull, hi4 = 0;
+        for (int wg = 0; wg < 256; ++wg) {
+            const unsigned long long* t = &st[(size_t)wg * 16 * 8];
+            if (!t[0]) continue;
+            lo0 = t[0] < lo0 ? t[0] : lo0; hi0 = t[0] > hi0 ? t[0] : hi0;
+            unsigned long long last = 0;
+            for (int it = 0; it < 16; ++it) if (t[it * 8 + 4]) last = t[it * 8 + 4];
+            lo4 = last < lo4 ? last : lo4; hi4 = last > hi4 ? last : hi4;
+        }
+        printf("  first K-loop start spread %llu cycles, last store issue spread %llu cycles, kernel span %llu cycles\n", hi0 - lo0, hi4 - lo4, hi4 - lo0);
+    }
+}
+
 int main(int argc, char** argv) {
     printf("leclip ABI %d\n", leclip_abi_version());
     if (argc > 1 && !strcmp(argv[1], "bench")) { bench(); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "stamps")) { stamps(); return 0; }
     check_gemm_identity();
     for (int dt : {LECLIP_BF16, LECLIP_F16}) {
         check_gemm(200, 128, 64, dt, LECLIP_F32, LECLIP_F32, 0, false, false);
