@@ -52,6 +52,7 @@ struct Gemm256Args {
     int tiles_n, tiles_total;
     int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
     unsigned long long* stamps;   // diagnostic build (-DLECLIP_GEMM_STAMPS) only: s_memtime stamps, [workgroup][16 tiles][8]
+    int no_xtile;      // 1: do not pipeline the K-loop across output tiles (LECLIP_GEMM_NO_XTILE, A/B timing)
     int strict_wait;   // 1: never relax the first K-tile's vmcnt waits past the previous epilogue's stores (A/B timing)
     int dbg;   // diagnostic: 1 skip epilogue, 2 skip global stores, 4 skip K-loop (LECLIP_GEMM_DEBUG; timing experiments only)
 };
@@ -134,36 +135,47 @@ struct PP {
     // (which only need prologue DMA, older than those stores) may leave X more operations outstanding: the stores get
     // a whole K-tile to be acknowledged instead of stalling the first MFMA cluster.  Chosen at run time (t == 0) by a
     // scalar branch around the two s_waitcnt forms: a peeled copy of the K-tile costs registers (hoisted addresses).
-    template <int V, int X = 0>
-    __device__ __forceinline__ void ktile(int t) {
+    // nx (wave-uniform, run time): this workgroup continues with another output tile and the K-loop is pipelined ACROSS
+    // the tile boundary - the LDS-DMA slots that the last two K-tiles no longer need for this tile are filled with the
+    // next tile's K-tile 0 (k0 in the second-to-last K-tile, k1 in the last), at the same phases and into the same
+    // slots as in the steady state (requires an even K-tile count, so that the stage parity lines up).  `next_src`
+    // re-points a_src / w_src at the next tile's rows once this tile's last DMA has been issued.
+    template <int V, int X = 0, class F>
+    __device__ __forceinline__ void ktile(int t, bool nx, F&& next_src) {
         const int s = t & 1;
         const int k1 = (t + 1) * TK, k2 = (t + 2) * TK;
         // ---- phase 0: (k0, r0)
         read_a(s, 0, 0);
         read_b(s, 0);
         if (V <= 1) stage_b(1 - s, 1, k1 + 32);
+        else if (nx) stage_b(1 - s, 1, 32);
         PIN();
         compute(0);
         // ---- phase 1: (k0, r1)
         read_a(s, 0, 1);
         if (V <= 1) stage_a(1 - s, 1, k1 + 32);
-        if (V <= 1) {   // k1 slots of tile t landed (this wave's pieces)
+        else if (nx) stage_a(1 - s, 1, 32);
+        if (V <= 1 || nx) {   // k1 slots of tile t landed (this wave's pieces)
             if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         PIN();
         compute(1);
+        if (V == 1 && nx) next_src();
         // ---- phase 2: (k1, r0)
         read_a(s, 1, 0);
         read_b(s, 1);
         if (V == 0) stage_b(s, 0, k2);
+        else if (V == 1 && nx) stage_b(s, 0, 0);
         PIN();
         compute(0);
         // ---- phase 3: (k1, r1)
         read_a(s, 1, 1);
         if (V == 0) stage_a(s, 0, k2);
-        if (V == 0) {   // k0 slots of tile t+1 landed
+        else if (V == 1 && nx) stage_a(s, 0, 0);
+        if (V == 0 || (V == 1 && nx)) {   // k0 slots of tile t+1 landed
             if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         } else if (V == 1) {
@@ -261,8 +273,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         m0 = (int64_t)tm * TM;
         n0 = tn * TN;
     };
-    // first K-tiles of a tile: tile 0 completely, tile 1's k0 slots; 12 LDS-DMA per wave
-    auto prologue = [&](int64_t m0, int n0) {
+    // per-lane global sources of the two LDS-DMA pieces this wave contributes to every A / B slot of a tile
+    auto set_sources = [&](int64_t m0, int n0) {
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int r = (wave + 8 * u) * 16 + dma_r;
@@ -271,6 +283,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             p.a_src[u] = (const T*)g.A + ar * g.lda + dma_c;
             p.w_src[u] = (const T*)g.W + (int64_t)(n0 + r) * g.ldw + dma_c;
         }
+    };
+    // first K-tiles of a tile: K-tile 0 completely, K-tile 1's k0 slots; 12 LDS-DMA per wave
+    auto prologue = [&]() {
         p.stage_b(0, 0, 0);
         p.stage_a(0, 0, 0);
         p.stage_b(0, 1, 32);
@@ -293,9 +308,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     int64_t m0;
     int n0;
     tile_origin(v, m0, n0);
-    prologue(m0, n0);
+    set_sources(m0, n0);
+    prologue();
+    // Cross-tile pipelining (see PP::ktile): an even number of K-tiles keeps the stage parity across the tile boundary.
+    const bool pipelined = (nk & 1) == 0 && !(g.dbg & 4) && !g.no_xtile;
     // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 16 partial-sum pairs)
-    constexpr int EPI_STORES = CFG >= 0 ? 16 * (1 + ((CFG >> 1) & 1)) : 0;
+    // (+ the 8 loads of the second residual batch, which are younger than the next tile's prologue DMA as well)
+    constexpr int EPI_STORES = CFG >= 0 ? 16 * (1 + ((CFG >> 1) & 1)) + (PF == 1 ? 8 : 0) : 0;
     int tile_it = 0;
     (void)tile_it;
     bool drain = CFG >= 0;   // false: the previous tile ended with exactly EPI_STORES stores after this tile's prologue DMA
@@ -321,12 +340,19 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         PIN();
 
         STAMP(0);
+        const int vn = v + gridDim.x;
+        const bool more = vn < g.tiles_total;
+        const bool nx = more && pipelined;
+        int64_t m0n = 0;
+        int n0n = 0;
+        if (nx) tile_origin(vn, m0n, n0n);
+        auto next_src = [&] { set_sources(m0n, n0n); };
         int t = 0;
         if (g.dbg & 4) t = nk - 2 > 0 ? nk - 2 : 0;
-        for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t);
-        p.template ktile<1, EPI_STORES>(t);
+        for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
+        p.template ktile<1, EPI_STORES>(t, nx, next_src);
 
-        p.template ktile<2>(t + 1);
+        p.template ktile<2>(t + 1, nx, next_src);
         STAMP(1);
 
         // Epilogue operands (bias, LayerNorm column sums, and - for the whole tile, 16 chunks per lane - the 16-bit
@@ -337,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         int lane_e = lane;   // laundered: everything derived from it is recomputed per tile instead of being hoisted out of
         // the persistent loop as per-lane invariants that do not fit beside the K-loop's registers.  (Not for the residual
         // prefetch: its 16 row addresses are cheaper as hoisted base + scalar offsets than recomputed all at once.)
-        if constexpr (PF != 1) asm volatile("" : "+v"(lane_e));
+        asm volatile("" : "+v"(lane_e));
         const int crow = lane_e >> 3, ccol = (lane_e & 7) * 8;
         const int n = en0 + wn * 64 + ccol;
         float b8[8], s8[8];
@@ -358,14 +384,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         // two of the wave's 16 row slots - lane (crow, c) holds rows c*16 + crow and c*16 + 8 + crow - and a pass fetches
         // its pair from lane c = q of its 8-lane group with ds_bpermute (4 VGPRs instead of 32)
         f32x2 lnpre[PF == 2 ? 2 : 1];
+        // residual: 16-byte chunk qu of this lane.  Fetched in two batches of 8 (= 32 VGPRs each): the first here, the
+        // second from inside the epilogue once the first two accumulator strips are parked and their registers are free,
+        // but still ahead of the first output store (vmcnt retires in order: a load behind stores waits for them).
+        auto load_res = [&](int qu, int crow, int n) {
+            int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
+            m = m < g.M ? m : g.M - 1;
+            return *(const i32x4*)((const char*)e.res + (m * e.ldr + n) * 2);   // (specialised path: no row remap)
+        };
         if constexpr (PF == 1) {
 #pragma unroll
-            for (int qu = 0; qu < 16; ++qu) {
-                int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
-                m = m < g.M ? m : g.M - 1;
-                const int64_t rrow = e.rowmap_P ? m % e.rowmap_P + 1 : m;
-                rpre[qu] = *(const i32x4*)((const char*)e.res + (rrow * e.ldr + n) * 2);
-            }
+            for (int qu = 0; qu < 8; ++qu) rpre[qu] = load_res(qu, crow, n);
         }
         if constexpr (PF == 2) {
 #pragma unroll
@@ -380,8 +409,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         PIN();
         __syncthreads();                             // every wave is done reading the K-loop buffers
 
-        const int vn = v + gridDim.x;
-        const bool more = vn < g.tiles_total;
         // Wait for them once, here, and launder the registers through empty asm statements so that hipcc sees their
         // definitions as complete: otherwise it guards every use inside the store loop with a conservative vmcnt(0) (it
         // cannot count the stores of the branchy store code; vmcnt retires loads and stores in order, so each such wait
@@ -391,17 +418,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         for (int c = 0; c < 8; ++c) { asm volatile("" : "+v"(b8[c])); asm volatile("" : "+v"(s8[c])); }
         if constexpr (PF == 1) {
 #pragma unroll
-            for (int qu = 0; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
+            for (int qu = 0; qu < 8; ++qu) asm volatile("" : "+v"(rpre[qu]));
         }
         if constexpr (PF == 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(lnpre[u]));
         }
         STAMP(2);
-        if (more) {   // next tile's first K-tiles: their HBM/L2 latency overlaps this tile's epilogue
-            tile_origin(vn, m0, n0);
-            prologue(m0, n0);
+        if (nx) {   // K-tile 0 of the next tile is already in LDS / in flight (issued inside the last two K-tiles): add K-tile 1's k0 slots
+            p.stage_b(1, 0, TK);
+            p.stage_a(1, 0, TK);
+        } else if (more) {   // not pipelined (odd K-tile count): the whole prologue, its latency overlaps this tile's epilogue
+            tile_origin(vn, m0n, n0n);
+            set_sources(m0n, n0n);
+            prologue();
         }
+        m0 = m0n;
+        n0 = n0n;
         STAMP(3);
 
         // ---- epilogue: 8 passes of 16 rows.  The wave parks a 16x64 fp32 strip in its own 4 KiB staging region
@@ -425,15 +458,34 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) sq[r * 64 + ((16 * j) ^ wsw)] = p.acc[q >> 2][q & 3][j][r];
                 };
-                const int64_t row_base = em0 + wm * 128 + crow;
-                T* optr = (T*)e.out + row_base * e.ldy + n;
-                float* sptr = STATS ? e.stats_out + (row_base * e.stats_slots + (n >> 6)) * 2 : nullptr;
-                const int rd_off[2] = {crow * 64 + (ccol ^ (((crow >> 2) & 1) << 4)), (8 + crow) * 64 + (ccol ^ ((((8 + crow) >> 2) & 1) << 4))};
                 auto passes = [&](auto check, auto nostore) {
                     park(0);
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         if (q + 1 < 8) park(q + 1);
+                        // Row / column addressing is rebuilt in every pass from a laundered lane id (a dozen VALU
+                        // instructions): kept across the passes - or hoisted out of the persistent loop - the 64-bit
+                        // pointers do not fit beside the accumulators and get spilled to scratch.
+                        int lane_q = lane_e;
+                        asm volatile("" : "+v"(lane_q));
+                        const int crow = lane_q >> 3, ccol = (lane_q & 7) * 8;
+                        const int n = en0 + wn * 64 + ccol;
+                        const int64_t row_base = em0 + wm * 128 + crow;
+                        T* optr = (T*)e.out + row_base * e.ldy + n;
+                        float* sptr = STATS ? e.stats_out + (row_base * e.stats_slots + (n >> 6)) * 2 : nullptr;
+                        const int rd_off[2] = {crow * 64 + (ccol ^ (((crow >> 2) & 1) << 4)), (8 + crow) * 64 + (ccol ^ ((((8 + crow) >> 2) & 1) << 4))};
+                        if constexpr (PF == 1) {
+                            if (q == 0) {   // second residual batch: issued before any store of this tile
+#pragma unroll
+                                for (int qu = 8; qu < 16; ++qu) rpre[qu] = load_res(qu, crow, n);
+                            }
+                            if (q == 4) {   // ... and needed from here on: everything but the stores issued since must be back
+                                if (decltype(check)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (store count varies)
+                                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (1 + STATS)) : "memory");
+#pragma unroll
+                                for (int qu = 8; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
+                            }
+                        }
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const float* sp = st + (q & 1) * (EPI_WAVE_BYTES / 4) + rd_off[u];
@@ -446,7 +498,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                             if (decltype(nostore)::value && vv[0] != 12345.678f) continue;
                             f32x2 ln = lnpre[0];
                             if constexpr (PF == 2) {
-                                const int src = ((lane_e & ~7) | q) << 2;   // byte address of the source lane
+                                const int src = ((lane_q & ~7) | q) << 2;   // byte address of the source lane
                                 // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
                                 const float mean_l = lnpre[u][0], rstd_l = lnpre[u][1];
                                 ln[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mean_l)));
@@ -570,6 +622,8 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     static const int desync = [] { const char* e = getenv("LECLIP_GEMM_DESYNC"); return e ? atoi(e) : 0; }();
     a.desync = desync;
     a.stamps = g_stamps;
+    static const int no_xtile = [] { const char* e = getenv("LECLIP_GEMM_NO_XTILE"); return e ? atoi(e) : 0; }();
+    a.no_xtile = no_xtile;
     static const int strict_wait = [] { const char* e = getenv("LECLIP_GEMM_STRICT_WAIT"); return e ? atoi(e) : 0; }();
     a.strict_wait = strict_wait;
     return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
