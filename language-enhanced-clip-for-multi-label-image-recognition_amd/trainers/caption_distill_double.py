@@ -176,6 +176,36 @@ class CustomCLIP(nn.Module):
         self.dtype = clip_model.dtype
         self.model = clip_model
         self._text_cache = None  # (ctx version, features): prompts are constant between updates
+        # momentum ("EMA") copy of the prompt learner (reference :555-559 `_momentum_update`, :545-553 `copy_params`;
+        # cfg.TRAIN.ema / cfg.TRAIN.momentum): m <- momentum * m + (1 - momentum) * p after every training forward
+        self.ema = bool(cfg.TRAIN.get("ema", False))
+        self.momentum = float(cfg.TRAIN.get("momentum", 0.999))
+        if self.ema:
+            import copy
+            self.prompt_learner_m = copy.deepcopy(self.prompt_learner)
+            self.model_pairs = [[self.prompt_learner, self.prompt_learner_m]]
+            self.copy_params()
+
+    @torch.no_grad()
+    def copy_params(self):
+        for model, model_m in self.model_pairs:
+            for param, param_m in zip(model.parameters(), model_m.parameters()):
+                param_m.data.copy_(param.data)
+                param_m.requires_grad = False
+
+    @torch.no_grad()
+    def _momentum_update(self):
+        for model, model_m in self.model_pairs:
+            for param, param_m in zip(model.parameters(), model_m.parameters()):
+                param_m.data.mul_(self.momentum).add_(param.data, alpha=1.0 - self.momentum)
+
+    @torch.no_grad()
+    def momentum_logits(self, image_features: torch.Tensor, logit_scale: float = 4.0) -> torch.Tensor:
+        """Scores of the momentum prompts on already-encoded features (the `logits_m_` of reference :516-523)."""
+        from ..hip import ops
+        prompts = self.prompt_learner_m()[0]
+        feats = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))
+        return ops.l2norm_logits(image_features, feats, logit_scale)
 
     def class_text_features(self) -> torch.Tensor:
         ctx = self.prompt_learner.ctx
@@ -199,7 +229,12 @@ class CustomCLIP(nn.Module):
             prompts = self.prompt_learner()[0]
             text_features = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))
             self._text_cache = None
-            return CosineLogitsFunction.apply(image_features, text_features, logit_scale), None, None, None
+            logits = CosineLogitsFunction.apply(image_features, text_features, logit_scale)
+            logits_m = None
+            if self.ema:    # reference :516-523: update the momentum copy, score it without gradient
+                self._momentum_update()
+                logits_m = self.momentum_logits(image_features, logit_scale)
+            return logits, None, None, logits_m
         text_features = self.class_text_features()
         logits = ops.l2norm_logits(image_features, text_features, logit_scale)
         return logits, None, None, None
@@ -209,7 +244,7 @@ class CustomCLIP(nn.Module):
 class Caption_distill_double:
     """Trainer plug-in (reference :565-938) reduced to the hot path's callers: ``build_model``,
     ``model_inference``, ``test``, ``load_model`` / ``save_model`` with the reference's checkpoint layout.
-    ``forward_backward`` needs the text-tower backward kernels and is not built yet."""
+    ``forward_backward`` is the prompt-tuning step on the text-tower backward kernels."""
 
     def __init__(self, cfg, classnames: Optional[List[str]] = None, test_loader=None, evaluator=None):
         self.cfg = cfg
@@ -243,7 +278,7 @@ class Caption_distill_double:
         name = cfg.TRAIN.get("MODEL_NAME", "default")
         model = CustomCLIP(cfg, self.classnames, clip_model)
         for pname, param in model.named_parameters():       # reference :762-765
-            param.requires_grad_("prompt_learner" in pname)
+            param.requires_grad_("prompt_learner." in pname and "prompt_learner_m." not in pname)
         model.to(self.device)
         model.eval()
         self._models[name] = model

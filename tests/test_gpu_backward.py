@@ -180,3 +180,30 @@ def test_trainer_forward_backward_reduces_loss(ops, golden_dir):
     with torch.no_grad():
         out = tr.model_inference(torch.from_numpy(synth.make_images(2, 32, seed=1)).to(tr.device), "default")[0]
     assert out.shape == (2, 80)
+
+
+def test_trainer_momentum_copy_follows_the_prompts(ops, golden_dir):
+    """cfg.TRAIN.ema: after every training forward the momentum prompts move toward the tuned prompts and their
+    no-grad scores come back in the fourth output slot (reference CDD.py:516-523, 555-559)."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    torch.manual_seed(0)
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "OPTIM.LR", "0.0002", "OPTIM.WARMUP_EPOCH", "0", "TRAIN.ema", "True",
+                         "TRAIN.momentum", "0.5"])
+    tr = build_trainer(cfg)
+    model = tr.model_default
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    caps = torch.from_numpy(t["tokens_photo"][:8])
+    labels = torch.zeros(8, 80)
+    labels[torch.arange(8), torch.arange(8)] = 1.0
+    m0 = model.prompt_learner_m.ctx.detach().clone()
+    for _ in range(3):
+        tr.forward_backward({"img": caps, "label": labels})
+    model.train()
+    out = model(None, caps.to(tr.device))
+    assert out[3] is not None and out[3].shape == (8, 80) and bool(torch.isfinite(out[3]).all()) and not out[3].requires_grad
+    gap0 = float((m0 - model.prompt_learner.ctx.detach()).norm())
+    gap1 = float((model.prompt_learner_m.ctx - model.prompt_learner.ctx.detach()).norm())
+    assert gap1 < gap0 and not model.prompt_learner_m.ctx.requires_grad

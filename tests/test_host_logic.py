@@ -190,6 +190,26 @@ def test_config_registry_and_checkpoint_layout(tmp_path):
         tr.load_model(str(tmp_path), epoch=99)
 
 
+def test_momentum_prompt_copy():
+    """cfg.TRAIN.ema: the momentum copy starts equal to the prompt learner, is frozen, and follows
+    m <- momentum * m + (1 - momentum) * p (reference CDD.py:545-559)."""
+    from leclip_amd.registry import build_trainer
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "TRAIN.ema", "True", "TRAIN.momentum", "0.9"])
+    model = build_trainer(cfg).model_default
+    pl, pm = model.prompt_learner, model.prompt_learner_m
+    assert all(not q.requires_grad for q in pm.parameters()) and all(q.requires_grad for q in pl.parameters())
+    assert all(torch.equal(a, b) for a, b in zip(pl.parameters(), pm.parameters()))
+    before = pm.ctx.detach().clone()
+    with torch.no_grad():
+        pl.ctx.add_(1.0)
+    model._momentum_update()
+    torch.testing.assert_close(pm.ctx, 0.9 * before + 0.1 * pl.ctx.detach())
+    model.copy_params()
+    assert torch.equal(pm.ctx, pl.ctx)
+
+
 def test_evaluator_matches_reference_kats(golden_dir):
     from leclip_amd.evaluation import MLClassification, average_precision, mAP
     g = np.load(os.path.join(golden_dir, "metrics_kat.npz"))
