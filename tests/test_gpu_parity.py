@@ -155,6 +155,22 @@ def test_attention(ops, dt, cfg):
     np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-5, 4e-3, 2.5e-2), rtol=0)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(86, 197, 12), (43, 224, 24), (22, 193, 48), (300, 197, 12)])
+def test_attention_many_heads(ops, dt, cfg):
+    """>= 1024 (batch, head) pairs with 193..224 tokens run the persistent pipelined kernel (attn_heads_kernel): head counts
+    that are not a multiple of the CU count leave workgroups with different numbers of heads."""
+    b, t, h = cfg
+    d = 64 * h
+    qkv = _rand((b * t, 3 * d), 31).to(dt)
+    y = ops.attention(qkv.to(DEV), b, t, h, False)
+    q, k, v = [z.reshape(b, t, h, 64).transpose(1, 2) for z in qkv.to(DEV).float().split(d, dim=-1)]
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(b * t, d)   # fp32 torch on the same device
+    err = float((y.float() - ref).abs().max())
+    assert err <= _tol(dt, 2e-5, 4e-3, 2.5e-2), err
+    assert torch.equal(y, ops.attention(qkv.to(DEV), b, t, h, False))     # deterministic
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gather_ln_proj_and_logits(ops, dt):
     from oracle import clip_oracle as co
