@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph on the steps that are not profiled")
+    ap.add_argument("--profile-every", type=int, default=4, help="record per-kernel HIP events on every N-th timed step (0 = never)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams (kernel tails of one "
                     "half overlap the other half's kernels)")
@@ -118,14 +120,29 @@ def main():
         for _ in range(args.warmup):
             out = step()
         fence()
+        graph = None
+        if args.graph and world == 1 and args.streams == 1:
+            # the ~105 launches of one step captured once (the C-ABI launches go to torch's current stream, which is the
+            # capturing stream here); replayed with one hipGraphLaunch per step
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                gout = step()
+            fence()
         prof = []
-        ops.set_profile(prof)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = step()
+        for i in range(args.steps):
+            # per-kernel HIP events on every `--profile-every`-th step of the timed region (a pair of event records around
+            # each launch costs a few microseconds of GPU idle; sampling keeps the measured rate honest)
+            sampled = args.profile_every > 0 and i % args.profile_every == 0
+            ops.set_profile(prof if sampled else None)
+            if graph is not None and not sampled:
+                graph.replay()
+                out = gout
+            else:
+                out = step()
+        ops.set_profile(None)
         fence()
         dt = time.perf_counter() - t0
-        ops.set_profile(None)
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -142,7 +159,8 @@ def main():
         f[3] += 1
     g = fam.get("gemm", [1e-9, 0, 0, 1])
     gemm_tflops = g[1] / g[0] * 1e-12
-    kernels = {k: {"launches_per_step": v[3] // args.steps, "avg_us": v[0] / v[3] * 1e6,
+    prof_steps = len(range(0, args.steps, args.profile_every)) if args.profile_every > 0 else 1
+    kernels = {k: {"launches_per_step": v[3] // prof_steps, "avg_us": v[0] / v[3] * 1e6,
                    "tflops": v[1] / v[0] * 1e-12, "alg_gbs": v[2] / v[0] * 1e-9} for k, v in fam.items()}
 
     ips = world * B * args.steps / dt
