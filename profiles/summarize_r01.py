@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_r01_final")
 
 def counters(sub):
-    f = glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(SRC, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)   # newest run
     per = collections.defaultdict(lambda: collections.defaultdict(float))
     for r in csv.DictReader(open(f)):
         per[(r["Kernel_Name"], r["Dispatch_Id"])][r["Counter_Name"]] += float(r["Counter_Value"])
@@ -20,7 +20,7 @@ def by_kernel(per, match):
                 agg[k].append(v)
     return {k: sum(v) / len(v) for k, v in agg.items()}, max((len(v) for v in agg.values()), default=0)
 
-stats = glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(SRC, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)
 rows = list(csv.DictReader(open(stats)))
 with open(os.path.join(ROOT, "profiles", "r01_kernel_stats.csv"), "w") as f:
     w = csv.writer(f)
