@@ -166,7 +166,7 @@ def main():
     ips = world * B * args.steps / dt
     fpi = flops_per_image(arch)
     result = {
-        "metric": "images/sec (multi-label forward, B=256, 224x224)", "value": ips, "unit": "img/s", "n_gpus": world,
+        "metric": f"images/sec (multi-label forward, B={B}, {arch.image_resolution}x{arch.image_resolution})", "value": ips, "unit": "img/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.arch} image tower + 80 learnable-prompt class features (cached) -> x4.0 cosine logits, "
