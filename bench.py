@@ -46,7 +46,7 @@ def main():
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph on the steps that are not profiled")
-    ap.add_argument("--profile-every", type=int, default=4, help="record per-kernel HIP events on every N-th timed step (0 = never)")
+    ap.add_argument("--profile-every", type=int, default=10, help="record per-kernel HIP events on every N-th timed step (0 = never)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams (kernel tails of one "
                     "half overlap the other half's kernels)")
