@@ -109,88 +109,109 @@ __global__ __launch_bounds__(256) void quickgelu_kernel(const T* __restrict__ pr
 
 // ---------------------------------------------------------------------------------------------- attention backward
 // One 256-thread workgroup per (batch, head), T <= 104, head_dim 64.  Q, K, V, dO of the head in LDS as fp32 (rows
-// padded to 65), probabilities recomputed:  P = softmax(scale QK^T + mask);  dV = P^T dO;  dP = dO V^T;
-// dS = P o (dP - rowsum(P o dP));  dQ = scale dS K;  dK = scale dS^T Q.   fp32 arithmetic for every I/O dtype.
-constexpr int AB_TMAX = 104;   // 4 x T x 65 + T x (T+1) floats of LDS <= 160 KiB
+// of 68 floats: 16-byte aligned, so every contraction over d reads float4), probabilities recomputed:
+//   P = softmax(scale QK^T + mask);  dV = P^T dO;  D = rowsum(dO o O) with O = P V recomputed (so dP is never stored);
+//   dS = scale P o (dO V^T - D), in place over P;  dQ = dS K;  dK = dS^T Q.       fp32 arithmetic for every I/O dtype.
+// Every phase is spread over all 256 threads: (q,k) pairs for the two T x T phases, (row, 4 head dims) for the four
+// T x 64 phases (a lane keeps 4 accumulators, the T x T operand is an LDS broadcast), one wave per row for softmax.
+constexpr int AB_TMAX = 104;   // 4 x T x 68 + T x (T+1) + T floats of LDS <= 160 KiB
+constexpr int AB_LD = 68;
+
+__device__ __forceinline__ float dot64(const float* a, const float* b) {
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+        const f32x4 x = *(const f32x4*)(a + 4 * c), y = *(const f32x4*)(b + 4 * c);
+        acc = fmaf(x[0], y[0], acc); acc = fmaf(x[1], y[1], acc); acc = fmaf(x[2], y[2], acc); acc = fmaf(x[3], y[3], acc);
+    }
+    return acc;
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
                                                        int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale, int causal) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sQ = sm;
-    float* sK = sQ + Tn * 65;
-    float* sV = sK + Tn * 65;
-    float* sO = sV + Tn * 65;          // dO
-    float* sP = sO + Tn * 65;          // [T][T+1]  P, then dS
+    float* sK = sQ + Tn * AB_LD;
+    float* sV = sK + Tn * AB_LD;
+    float* sO = sV + Tn * AB_LD;          // dO
+    float* sP = sO + Tn * AB_LD;          // [T][T+1]  P, then dS
     const int LP = Tn + 1;
-    const int tid = threadIdx.x;
+    float* sD = sP + Tn * LP;             // [T]  D[q] = dO[q] . O[q]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
     const int d_model = heads * 64;
     const T* base = qkv + (int64_t)b * Tn * ld_qkv + h * 64;
     const T* dob = dout + (int64_t)b * Tn * ld_out + h * 64;
-    for (int i = tid; i < Tn * 64; i += 256) {
-        const int r = i >> 6, c = i & 63;
-        sQ[r * 65 + c] = (float)base[(int64_t)r * ld_qkv + c];
-        sK[r * 65 + c] = (float)base[(int64_t)r * ld_qkv + d_model + c];
-        sV[r * 65 + c] = (float)base[(int64_t)r * ld_qkv + 2 * d_model + c];
-        sO[r * 65 + c] = (float)dob[(int64_t)r * ld_out + c];
+    T* dqb = dqkv + (int64_t)b * Tn * ld_qkv + h * 64;
+    const int items = Tn * 16;            // (row, group of 4 head dims)
+    for (int i = tid; i < items; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        *(f32x4*)(sQ + r * AB_LD + c) = ld4<T>(base + (int64_t)r * ld_qkv + c);
+        *(f32x4*)(sK + r * AB_LD + c) = ld4<T>(base + (int64_t)r * ld_qkv + d_model + c);
+        *(f32x4*)(sV + r * AB_LD + c) = ld4<T>(base + (int64_t)r * ld_qkv + 2 * d_model + c);
+        *(f32x4*)(sO + r * AB_LD + c) = ld4<T>(dob + (int64_t)r * ld_out + c);
     }
     __syncthreads();
     // scores
     for (int i = tid; i < Tn * Tn; i += 256) {
         const int q = i / Tn, k = i - q * Tn;
-        float s = -3.0e38f;
-        if (!causal || k <= q) {
-            float dot = 0.f;
-            for (int d = 0; d < 64; ++d) dot = fmaf(sQ[q * 65 + d], sK[k * 65 + d], dot);
-            s = dot * scale;
-        }
-        sP[q * LP + k] = s;
+        sP[q * LP + k] = (!causal || k <= q) ? dot64(sQ + q * AB_LD, sK + k * AB_LD) * scale : -3.0e38f;
     }
     __syncthreads();
-    // row softmax (one thread per query row)
-    for (int q = tid; q < Tn; q += 256) {
-        float mx = -3.0e38f;
-        for (int k = 0; k < Tn; ++k) mx = fmaxf(mx, sP[q * LP + k]);
-        float sum = 0.f;
-        for (int k = 0; k < Tn; ++k) { const float p = sP[q * LP + k] > -1.0e38f ? expf(sP[q * LP + k] - mx) : 0.f; sP[q * LP + k] = p; sum += p; }
-        const float inv = 1.0f / sum;
-        for (int k = 0; k < Tn; ++k) sP[q * LP + k] *= inv;
+    // row softmax: one wave per query row, two keys per lane (T <= 128)
+    for (int q = wave; q < Tn; q += 4) {
+        float* row = sP + q * LP;
+        const float s0 = lane < Tn ? row[lane] : -3.0e38f, s1 = lane + 64 < Tn ? row[lane + 64] : -3.0e38f;
+        const float mx = wave_max(fmaxf(s0, s1));
+        const float p0 = s0 > -1.0e38f ? expf(s0 - mx) : 0.f, p1 = s1 > -1.0e38f ? expf(s1 - mx) : 0.f;
+        const float inv = 1.0f / wave_sum(p0 + p1);
+        if (lane < Tn) row[lane] = p0 * inv;
+        if (lane + 64 < Tn) row[lane + 64] = p1 * inv;
     }
     __syncthreads();
-    // dV[k][d] = sum_q P[q][k] dO[q][d]
-    T* dqb = dqkv + (int64_t)b * Tn * ld_qkv + h * 64;
-    for (int i = tid; i < Tn * 64; i += 256) {
-        const int k = i >> 6, d = i & 63;
-        float acc = 0.f;
-        for (int q = 0; q < Tn; ++q) acc = fmaf(sP[q * LP + k], sO[q * 65 + d], acc);
-        dqb[(int64_t)k * ld_qkv + 2 * d_model + d] = (T)acc;
-    }
-    __syncthreads();
-    // dS = P o (dP - D),  dP[q][k] = dO[q] . V[k],  D[q] = sum_k P[q][k] dP[q][k]   (one thread per row keeps it simple)
-    for (int q = tid; q < Tn; q += 256) {
-        float D = 0.f;
-        for (int k = 0; k < Tn; ++k) {
-            float dp = 0.f;
-            for (int d = 0; d < 64; ++d) dp = fmaf(sO[q * 65 + d], sV[k * 65 + d], dp);
-            D = fmaf(sP[q * LP + k], dp, D);
-        }
-        for (int k = 0; k < Tn; ++k) {
-            float dp = 0.f;
-            for (int d = 0; d < 64; ++d) dp = fmaf(sO[q * 65 + d], sV[k * 65 + d], dp);
-            sP[q * LP + k] = sP[q * LP + k] * (dp - D) * scale;
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < Tn * 64; i += 256) {
-        const int r = i >> 6, d = i & 63;
-        float aq = 0.f, ak = 0.f;
+    // dV[k][d] = sum_q P[q][k] dO[q][d];   D[q] = sum_d dO[q][d] * (sum_k P[q][k] V[k][d])
+    for (int i0 = 0; i0 < items; i0 += 256) {          // uniform trip count: the 16-lane reduction below needs whole groups
+        const int i = i0 + tid;
+        const bool live = i < items;
+        const int r = live ? i >> 4 : 0, c = (i & 15) * 4;
+        f32x4 dv = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < Tn; ++j) {
-            aq = fmaf(sP[r * LP + j], sK[j * 65 + d], aq);     // dQ[r] = sum_k dS[r][k] K[k]
-            ak = fmaf(sP[j * LP + r], sQ[j * 65 + d], ak);     // dK[r] = sum_q dS[q][r] Q[q]
+            const float pt = sP[j * LP + r];                // P[q = j][k = r]
+            const float pr = sP[r * LP + j];                // P[q = r][k = j]
+            const f32x4 g = *(const f32x4*)(sO + j * AB_LD + c), v = *(const f32x4*)(sV + j * AB_LD + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { dv[e] = fmaf(pt, g[e], dv[e]); o[e] = fmaf(pr, v[e], o[e]); }
         }
-        dqb[(int64_t)r * ld_qkv + d] = (T)aq;
-        dqb[(int64_t)r * ld_qkv + d_model + d] = (T)ak;
+        const f32x4 g = *(const f32x4*)(sO + r * AB_LD + c);
+        float part = (o[0] * g[0] + o[1] * g[1]) + (o[2] * g[2] + o[3] * g[3]);
+#pragma unroll
+        for (int m = 1; m < 16; m <<= 1) part += __shfl_xor(part, m);
+        if (live) {
+            st4<T>(dqb + (int64_t)r * ld_qkv + 2 * d_model + c, dv);
+            if ((i & 15) == 0) sD[r] = part;
+        }
+    }
+    __syncthreads();
+    // dS[q][k] = scale * P[q][k] * (dO[q] . V[k] - D[q]), in place
+    for (int i = tid; i < Tn * Tn; i += 256) {
+        const int q = i / Tn, k = i - q * Tn;
+        const float pv = sP[q * LP + k];
+        sP[q * LP + k] = pv != 0.f ? pv * (dot64(sO + q * AB_LD, sV + k * AB_LD) - sD[q]) * scale : 0.f;
+    }
+    __syncthreads();
+    // dQ[r] = sum_k dS[r][k] K[k];   dK[r] = sum_q dS[q][r] Q[q]
+    for (int i = tid; i < items; i += 256) {
+        const int r = i >> 4, c = (i & 15) * 4;
+        f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < Tn; ++j) {
+            const float sr = sP[r * LP + j], sc = sP[j * LP + r];
+            const f32x4 kk = *(const f32x4*)(sK + j * AB_LD + c), qq = *(const f32x4*)(sQ + j * AB_LD + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { aq[e] = fmaf(sr, kk[e], aq[e]); ak[e] = fmaf(sc, qq[e], ak[e]); }
+        }
+        st4<T>(dqb + (int64_t)r * ld_qkv + c, aq);
+        st4<T>(dqb + (int64_t)r * ld_qkv + d_model + c, ak);
     }
 }
 
@@ -211,7 +232,7 @@ int gelu_launch(const void* pre, const void* du, void* out, int64_t n, bool bwd,
 template <typename T>
 int attn_bwd_launch(const void* qkv, const void* dout, void* dqkv, int64_t B, int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale,
                     int causal, hipStream_t s) {
-    const size_t lds = ((size_t)4 * Tn * 65 + (size_t)Tn * (Tn + 1)) * sizeof(float);
+    const size_t lds = ((size_t)4 * Tn * AB_LD + (size_t)Tn * (Tn + 1) + Tn) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -254,6 +275,10 @@ extern "C" int leclip_attention_bwd(const void* qkv, const void* dout, void* dqk
                                     int64_t ld_out, leclip_mask mask, float scale, leclip_dtype dtype, void* stream) {
     if (!qkv || !dout || !dqkv || B <= 0 || T <= 0 || heads <= 0 || ld_qkv < 3 * heads * 64 || ld_out < heads * 64 || !dtype_ok(dtype)) {
         leclip_set_error("attention_bwd: bad argument"); return LECLIP_E_INVALID;
+    }
+    if ((ld_qkv % 4) || (ld_out % 4) || ((uintptr_t)qkv & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dqkv & 15)) {
+        leclip_set_error("attention_bwd: qkv / dout / dqkv must be 16-byte aligned with leading dimensions that are multiples of 4");
+        return LECLIP_E_INVALID;
     }
     if (head_dim != 64 || T > AB_TMAX) { leclip_set_error("attention_bwd: head_dim must be 64 and T <= %d (text tower)", AB_TMAX); return LECLIP_E_UNSUPPORTED; }
     hipStream_t s = (hipStream_t)stream;
