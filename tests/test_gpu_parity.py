@@ -139,6 +139,42 @@ def test_gemm_inplace_residual_and_errors(ops):
         ops.gemm(a.cpu(), w.cpu())
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("shape", [(6160, 2048, 512), (50332, 768, 768)])
+def test_gemm256_specialised_epilogues(ops, dt, shape):
+    """Shapes with >= 192 tiles of 256x256 run the persistent kernel; each of its compile-time epilogues (bias, +QuickGELU,
+    +residual, +residual+LayerNorm partial sums, fused LayerNorm, fused LayerNorm+QuickGELU) against fp32 torch on the
+    device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a wave-quantisation tail on the 128 kernel."""
+    M, N, K = shape
+    g = torch.Generator(device="cpu").manual_seed(7)
+    a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    res = torch.randn(M, N, generator=g).to(dt).to(DEV)
+    stats = torch.stack([torch.randn(M, generator=g) * 0.1, torch.rand(M, generator=g) + 0.5], dim=1).contiguous().to(DEV)
+    colsum = torch.randn(N, generator=g).to(DEV)
+    assert ops._capi.load().leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)).decode().startswith("gemm_tn_256x256x64")
+    ref0 = a.float() @ w.float().t()
+    gelu = lambda x: x * torch.sigmoid(1.702 * x)
+    lnref = stats[:, 1:2] * (ref0 - stats[:, 0:1] * colsum[None, :]) + bias
+    tol = (2.0e-2 if dt == torch.bfloat16 else 2.5e-3)       # relative to the largest output magnitude (one 16-bit rounding)
+
+    def check(y, ref):
+        assert float((y.float() - ref).abs().max()) <= tol * max(float(ref.abs().max()), 1.0)
+
+    check(ops.gemm(a, w), ref0)
+    check(ops.gemm(a, w, bias), ref0 + bias)
+    check(ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU), gelu(ref0 + bias))
+    check(ops.gemm(a, w, bias, residual=res), ref0 + bias + res.float())
+    part = torch.zeros(M, N // 64, 2, device=DEV)
+    y = ops.gemm_ln(a, w, bias, residual=res, stats_out=part)
+    check(y, ref0 + bias + res.float())
+    yy = y.float().view(M, N // 64, 64)
+    assert float((part[..., 0] - yy.sum(-1)).abs().max()) <= 1e-3 and float((part[..., 1] - (yy * yy).sum(-1)).abs().max()) <= 2e-2
+    check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum), lnref)
+    check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=ops.ACT_QUICKGELU), gelu(lnref))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("cfg", [(2, 197, 12, False), (3, 77, 8, True), (2, 17, 2, False), (1, 50, 1, True), (2, 224, 1, False),
                                  (1, 1, 1, True)])
