@@ -23,6 +23,12 @@
 // LDS bank swizzle (64-byte rows, 4 rows per 256-byte bank row): 16-byte chunk c of row r is stored at chunk
 // c ^ f((r>>2)&3), f = {0,3,2,1}: every ds_read_b128 16-lane group then touches 16 distinct 16-byte slots.  The image
 // is lane-linear per LDS-DMA instruction, so the XOR is applied to the per-lane SOURCE address and to the read address.
+//
+// Epilogues (compile-time selected, see the kernel): "T16" for the kernels without residual - MFMA operands swapped so
+// a lane holds 4 consecutive columns, bias / fused LayerNorm / QuickGELU in the accumulator layout, finished 16-bit
+// values transposed through LDS with ds_write_b64; an fp32-staged specialised flavour for the residual kernels (16-bit
+// residual prefetched ahead of the first store, LayerNorm partial sums by DPP); a generic run-time-configured one for
+// the rest (fp32 output / residual, row remap).  All store full 128-byte lines, 16 bytes per lane.
 #include "leclip_common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -299,11 +305,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         p.stage_a(1, 0, TK);
     };
 
-    // Persistent over tiles: workgroup b takes virtual block ids b, b + grid, ...  The next tile's prologue DMA is
-    // issued before this tile's epilogue (the K-loop buffers are dead by then, the epilogue stages through its own
-    // 32 KiB), so its HBM/L2 latency and the epilogue's stores overlap.
-    // De-synchronise the CUs: all workgroups start together and would otherwise run K-loops and epilogues in
-    // lockstep, leaving HBM idle during the K-loops and saturated (MFMA idle) during the store bursts.
+    // Persistent over tiles: workgroup b takes virtual block ids b, b + grid, ...  With an even K-tile count the K-loop
+    // runs on across the tile boundary (PP::ktile, `nx`); otherwise the next tile's prologue DMA is issued before this
+    // tile's epilogue.  Either way K-tile 0 (+ K-tile 1's k0 slots) of the next tile is in LDS or in flight while the
+    // epilogue stages through the remaining 64 KiB.
+    // LECLIP_GEMM_DESYNC (diagnostic, measured to make no difference - DESIGN.md §6): start groups of workgroups late.
     if (g.desync) {
         const int groups = g.desync >> 8 ? g.desync >> 8 : 4;            // desync = groups * 256 + step (step in ~512-cycle units)
         const int phi = (blockIdx.x >> 3) % groups;
