@@ -363,6 +363,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
         p.template ktile<1, EPI_STORES>(t, nx, next_src);
 
+        // T16 flavour: the per-column constants (bias | fused-LayerNorm column sums: 2 x 256 floats per tile, one per
+        // thread) and the lane's two (mean, rstd) pairs are requested BEFORE the last K-tile - 1 + 4 registers, older than
+        // that K-tile's DMA, complete under its four phases - and the column constants reach the waves through LDS
+        // after the K-loop (as 10 loads per lane behind the last MFMA cluster they cost ~1 400 exposed cycles per tile).
+        float cpre = 0.f;
+        f32x2 lnq[2] = {{0.f, 1.f}, {0.f, 1.f}};
+        if constexpr (T16) {
+            const float* cp = tid < 256 ? e.bias : (PF == 2 ? e.ln_colsum : nullptr);
+            if (cp) cpre = cp[n0 + (tid & 255)];
+            if constexpr (PF == 2) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {   // lane (m = l & 15, g = l >> 4) keeps the rows of strips 2g and 2g + 1
+                    int64_t m = m0 + wm * 128 + (2 * (lane >> 4) + u) * 16 + (lane & 15);
+                    m = m < g.M ? m : g.M - 1;
+                    lnq[u] = *(const f32x2*)(e.ln_stats + 2 * m);
+                }
+            }
+        }
         p.template ktile<2>(t + 1, nx, next_src);
         STAMP(1);
 
@@ -379,29 +397,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         const int n = en0 + wn * 64 + ccol;
         // T16 flavour: bias / column sums for the lane's 16 accumulator columns 16j + 4g + r (g = lane >> 4)
         float b16[T16 ? 16 : 1], s16[T16 && PF == 2 ? 16 : 1];
-        if constexpr (T16) {
-            const int nb = en0 + wn * 64 + 4 * (lane_e >> 4);
-#pragma unroll
-            for (int c = 0; c < 16; ++c) b16[c] = 0.f;
-            if (e.bias) {   // one branch, four loads in flight together
-                f32x4 t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = *(const f32x4*)(e.bias + nb + 16 * j);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) b16[4 * j + r] = t[j][r];
-            }
-            if constexpr (PF == 2) {
-                f32x4 t[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) t[j] = *(const f32x4*)(e.ln_colsum + nb + 16 * j);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) s16[4 * j + r] = t[j][r];
-            }
-        }
         float b8[8], s8[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) { b8[c] = 0.f; s8[c] = 0.f; }
@@ -435,18 +430,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if constexpr (PF == 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                // fp32-staged flavour: lane (crow, c) keeps rows c*16 + u*8 + crow; T16 flavour (accumulator layout, lane
-                // (m = l & 15, g = l >> 4) works on row 16q + m of strip q): lane keeps the rows of strips 2g and 2g + 1
-                int64_t m = T16 ? em0 + wm * 128 + (2 * (lane_e >> 4) + u) * 16 + (lane_e & 15)
-                                : em0 + wm * 128 + (lane_e & 7) * 16 + u * 8 + crow;
-                m = m < g.M ? m : g.M - 1;
-                lnpre[u] = *(const f32x2*)(e.ln_stats + 2 * m);
+                if constexpr (T16) {
+                    lnpre[u] = lnq[u];   // requested before the last K-tile
+                } else {                 // fp32-staged flavour: lane (crow, c) keeps rows c*16 + u*8 + crow
+                    int64_t m = em0 + wm * 128 + (lane_e & 7) * 16 + u * 8 + crow;
+                    m = m < g.M ? m : g.M - 1;
+                    lnpre[u] = *(const f32x2*)(e.ln_stats + 2 * m);
+                }
             }
+        }
+        float* cst = (float*)(smem + 2 * STAGE_BYTES + 6144);   // bias[256] | colsum[256]: a gap in the epilogue region the strips leave free
+        if constexpr (T16) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("" : "+v"(cpre));
+            cst[tid] = cpre;
         }
         PIN();
         if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
         PIN();
-        __syncthreads();                             // every wave is done reading the K-loop buffers
+        __syncthreads();                             // every wave is done reading the K-loop buffers (and has published its constant)
+        if constexpr (T16) {
+            const float* cb = cst + wn * 64 + 4 * (lane_e >> 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 t4 = *(const f32x4*)(cb + 16 * j);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) b16[4 * j + r] = t4[r];
+                if constexpr (PF == 2) {
+                    const f32x4 c4 = *(const f32x4*)(cb + 256 + 16 * j);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s16[4 * j + r] = c4[r];
+                }
+            }
+        }
 
         // Wait for them once, here, and launder the registers through empty asm statements so that hipcc sees their
         // definitions as complete: otherwise it guards every use inside the store loop with a conservative vmcnt(0) (it
@@ -455,13 +471,6 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int c = 0; c < 8; ++c) { asm volatile("" : "+v"(b8[c])); asm volatile("" : "+v"(s8[c])); }
-        if constexpr (T16) {
-#pragma unroll
-            for (int c = 0; c < 16; ++c) {
-                asm volatile("" : "+v"(b16[c]));
-                if constexpr (PF == 2) asm volatile("" : "+v"(s16[c]));
-            }
-        }
         if constexpr (PF == 1) {
 #pragma unroll
             for (int qu = 0; qu < 8; ++qu) asm volatile("" : "+v"(rpre[qu]));
