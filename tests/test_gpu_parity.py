@@ -536,3 +536,29 @@ def test_score_postprocessing(ops):
     mn = ops.cooccurrence_matrix(adj, nums)
     got = ops.cooccurrence_adjust(torch.from_numpy(glob).to(DEV), mn.to(DEV)).cpu().numpy()
     np.testing.assert_allclose(got, mo.cooccurrence_adjust(glob.astype(np.float64), adj, nums), atol=2e-6, rtol=0)
+
+
+def test_rccl_gather_path_single_rank(tmp_path):
+    """The N>1 code path of parallel.py on the real backend: a one-rank RCCL ("nccl") process group in a child process,
+    all_gather_into_tensor on device tensors through parallel._gather_flat, and ShardedScorer end to end."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, torch, torch.distributed as dist
+        sys.path.insert(0, os.getcwd())
+        from leclip_amd import parallel
+        rank, world, local = parallel.init_from_env()
+        dist.init_process_group(backend="nccl", rank=0, world_size=1)
+        x = torch.arange(12, dtype=torch.float32, device="cuda").view(3, 4)
+        y = parallel._gather_flat(x, 1)
+        assert torch.equal(x, y)
+        sc = parallel.ShardedScorer(lambda im: im.float().mean(dim=(1, 2, 3))[:, None].expand(-1, 80).contiguous())
+        out = sc.score_global(torch.ones(5, 3, 8, 8, device="cuda"))
+        assert out.shape == (5, 80) and float(out.mean()) == 1.0
+        dist.barrier(); dist.destroy_process_group()
+        print("rccl ok")
+    """)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "rccl ok" in r.stdout, r.stderr[-2000:]
