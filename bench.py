@@ -280,6 +280,22 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
     m = {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(labels, ref), "hip": mAP(labels, hip),
          "max_abs_logit_diff": float(np.abs(ref - hip).max()),
          "top1_agree": float((ref.argmax(1) == hip.argmax(1)).mean())}
+    if args.dtype != "fp16":
+        # the reference's own GPU precision (clip.load keeps fp16 weights) on the same images: same kernels, same rate, 11-bit mantissa
+        from leclip_amd.clip import build_model
+        from leclip_amd.config import get_cfg_default
+        from leclip_amd.datasets import coco_object_categories
+        from leclip_amd.trainers import CustomCLIP
+        cfg = get_cfg_default()
+        cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+        c16 = CustomCLIP(cfg, coco_object_categories, build_model(sd))      # build_model returns fp16 weights like the reference
+        with torch.no_grad():
+            c16.prompt_learner.ctx.copy_(ctx)
+            c16.to(dev).eval()
+            h16 = np.concatenate([c16(torch.from_numpy(synth.make_images(cb, arch.image_resolution, seed=4321, start=i * cb)).to(dev),
+                                      if_test=True)[0].float().cpu().numpy() for i in range(n)])
+        m["hip_fp16"] = mAP(labels, h16)
+        m["max_abs_logit_diff_fp16"] = float(np.abs(ref - h16).max())
     return base, m
 
 
