@@ -108,14 +108,15 @@ __global__ __launch_bounds__(256) void quickgelu_kernel(const T* __restrict__ pr
 }
 
 // ---------------------------------------------------------------------------------------------- attention backward
-// One 256-thread workgroup per (batch, head), T <= 104, head_dim 64.  Q, K, V, dO of the head in LDS as fp32 (rows
+// One 1024-thread workgroup per (batch, head), T <= 104, head_dim 64.  Q, K, V, dO of the head in LDS as fp32 (rows
 // of 68 floats: 16-byte aligned, so every contraction over d reads float4), probabilities recomputed:
 //   P = softmax(scale QK^T + mask);  dV = P^T dO;  D = rowsum(dO o O) with O = P V recomputed (so dP is never stored);
 //   dS = scale P o (dO V^T - D), in place over P;  dQ = dS K;  dK = dS^T Q.       fp32 arithmetic for every I/O dtype.
-// Every phase is spread over all 256 threads: (q,k) pairs for the two T x T phases, (row, 4 head dims) for the four
+// Every phase is spread over all 1024 threads: (q,k) pairs for the two T x T phases, (row, 4 head dims) for the four
 // T x 64 phases (a lane keeps 4 accumulators, the T x T operand is an LDS broadcast), one wave per row for softmax.
 constexpr int AB_TMAX = 104;   // 4 x T x 68 + T x (T+1) + T floats of LDS <= 160 KiB
 constexpr int AB_LD = 68;
+constexpr int AB_THREADS = 1024;   // 4 waves per SIMD: the phases are fp32 VALU work, one wave per SIMD issues only every 4th cycle
 
 __device__ __forceinline__ float dot64(const float* a, const float* b) {
     float acc = 0.f;
@@ -128,7 +129,7 @@ __device__ __forceinline__ float dot64(const float* a, const float* b) {
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
+__global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
                                                        int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale, int causal) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* sQ = sm;
@@ -145,7 +146,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     const T* dob = dout + (int64_t)b * Tn * ld_out + h * 64;
     T* dqb = dqkv + (int64_t)b * Tn * ld_qkv + h * 64;
     const int items = Tn * 16;            // (row, group of 4 head dims)
-    for (int i = tid; i < items; i += 256) {
+    for (int i = tid; i < items; i += AB_THREADS) {
         const int r = i >> 4, c = (i & 15) * 4;
         *(f32x4*)(sQ + r * AB_LD + c) = ld4<T>(base + (int64_t)r * ld_qkv + c);
         *(f32x4*)(sK + r * AB_LD + c) = ld4<T>(base + (int64_t)r * ld_qkv + d_model + c);
@@ -154,13 +155,13 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
     __syncthreads();
     // scores
-    for (int i = tid; i < Tn * Tn; i += 256) {
+    for (int i = tid; i < Tn * Tn; i += AB_THREADS) {
         const int q = i / Tn, k = i - q * Tn;
         sP[q * LP + k] = (!causal || k <= q) ? dot64(sQ + q * AB_LD, sK + k * AB_LD) * scale : -3.0e38f;
     }
     __syncthreads();
     // row softmax: one wave per query row, two keys per lane (T <= 128)
-    for (int q = wave; q < Tn; q += 4) {
+    for (int q = wave; q < Tn; q += AB_THREADS / 64) {
         float* row = sP + q * LP;
         const float s0 = lane < Tn ? row[lane] : -3.0e38f, s1 = lane + 64 < Tn ? row[lane + 64] : -3.0e38f;
         const float mx = wave_max(fmaxf(s0, s1));
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
     __syncthreads();
     // dV[k][d] = sum_q P[q][k] dO[q][d];   D[q] = sum_d dO[q][d] * (sum_k P[q][k] V[k][d])
-    for (int i0 = 0; i0 < items; i0 += 256) {          // uniform trip count: the 16-lane reduction below needs whole groups
+    for (int i0 = 0; i0 < items; i0 += AB_THREADS) {          // uniform trip count: the 16-lane reduction below needs whole groups
         const int i = i0 + tid;
         const bool live = i < items;
         const int r = live ? i >> 4 : 0, c = (i & 15) * 4;
@@ -194,14 +195,14 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const T* __restrict__ qkv
     }
     __syncthreads();
     // dS[q][k] = scale * P[q][k] * (dO[q] . V[k] - D[q]), in place
-    for (int i = tid; i < Tn * Tn; i += 256) {
+    for (int i = tid; i < Tn * Tn; i += AB_THREADS) {
         const int q = i / Tn, k = i - q * Tn;
         const float pv = sP[q * LP + k];
         sP[q * LP + k] = pv != 0.f ? pv * (dot64(sO + q * AB_LD, sV + k * AB_LD) - sD[q]) * scale : 0.f;
     }
     __syncthreads();
     // dQ[r] = sum_k dS[r][k] K[k];   dK[r] = sum_q dS[q][r] Q[q]
-    for (int i = tid; i < items; i += 256) {
+    for (int i = tid; i < items; i += AB_THREADS) {
         const int r = i >> 4, c = (i & 15) * 4;
         f32x4 aq = {0.f, 0.f, 0.f, 0.f}, ak = {0.f, 0.f, 0.f, 0.f};
         for (int j = 0; j < Tn; ++j) {
@@ -238,7 +239,7 @@ int attn_bwd_launch(const void* qkv, const void* dout, void* dqkv, int64_t B, in
         (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3((unsigned)(B * heads)), dim3(256), lds, s, (const T*)qkv, (const T*)dout, (T*)dqkv, Tn, heads,
+    hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3((unsigned)(B * heads)), dim3(AB_THREADS), lds, s, (const T*)qkv, (const T*)dout, (T*)dqkv, Tn, heads,
                        ld_qkv, ld_out, scale, causal);
     return leclip_check_launch("attn_bwd_kernel");
 }
