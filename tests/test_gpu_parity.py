@@ -140,11 +140,12 @@ def test_gemm_inplace_residual_and_errors(ops):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("shape", [(6160, 2048, 512), (50332, 768, 768)])
+@pytest.mark.parametrize("shape", [(6160, 2048, 512), (50332, 768, 768), (50000, 512, 320), (49000, 512, 128)])
 def test_gemm256_specialised_epilogues(ops, dt, shape):
     """Shapes with >= 192 tiles of 256x256 run the persistent kernel; each of its compile-time epilogues (bias, +QuickGELU,
     +residual, +residual+LayerNorm partial sums, fused LayerNorm, fused LayerNorm+QuickGELU) against fp32 torch on the
-    device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a wave-quantisation tail on the 128 kernel."""
+    device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a wave-quantisation tail on the 128 kernel;
+    K = 320 has an odd number of K-tiles (no cross-tile pipelining: prologue between tiles), K = 128 the minimum of two."""
     M, N, K = shape
     g = torch.Generator(device="cpu").manual_seed(7)
     a = torch.randn(M, K, generator=g).to(dt).to(DEV)
