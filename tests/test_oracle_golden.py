@@ -106,3 +106,18 @@ def test_metric_kats(golden_dir):
     assert mo.ranking_loss(yp, yt, 1.0, 1.0) == pytest.approx(float(g["loss.ranking"]), rel=1e-5)
     assert mo.ranking_loss(yp, yt) == pytest.approx(float(g["loss.ranking_s2"]), rel=1e-5)
     assert mo.norm_logits_bce(yp, yt) == pytest.approx(float(g["loss.bce"]), rel=1e-5)
+
+
+def test_average_precision_against_independent_implementation():
+    """The oracle's AP (a restatement of dassl/evaluation/evaluator.py:137-154) against scikit-learn's
+    average_precision_score on tie-free random scores: an implementation that shares no code with either."""
+    from sklearn.metrics import average_precision_score
+    from oracle import metrics_oracle as mo
+    rng = np.random.default_rng(5)
+    for n in (7, 64, 500):
+        for frac in (0.05, 0.3, 0.9):
+            y = (rng.random(n) < frac).astype(np.int64)
+            if y.sum() == 0:
+                y[rng.integers(n)] = 1
+            s = rng.permutation(n).astype(np.float64) / n            # distinct scores: no tie-order convention involved
+            np.testing.assert_allclose(mo.average_precision(s, y), average_precision_score(y, s), rtol=0, atol=2e-8)   # (n_pos + 1e-8 in the denominator)
