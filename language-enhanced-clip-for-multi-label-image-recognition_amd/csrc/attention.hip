@@ -56,6 +56,24 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
         const int qi = qb * 32 + fr;
         const int qrow = qi < a.T ? qi : a.T - 1;
         f32x16 sc[NKT];
+        if constexpr (STORE_ALL) {
+            // pipelined kernel: K fragments one key tile (4 reads) ahead of their MFMAs - the wave's S -> softmax -> O chain,
+            // not HBM, is what bounds that kernel, so its LDS round trips are taken off the chain
+            v8 kfr[2][4];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) kfr[0][s] = *(const v8*)(kbase[s]);
+#pragma unroll
+            for (int kt = 0; kt < NKT; ++kt) {
+                if (kt + 1 < NKT) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) kfr[(kt + 1) & 1][s] = *(const v8*)(kbase[s] + (kt + 1) * 4096);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) sc[kt] = mfma_32x32x16(kfr[kt & 1][s], qf[s], sc[kt]);
+            }
+        } else {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
 #pragma unroll
@@ -67,6 +85,7 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                 const v8 kf = *(const v8*)(kbase[s] + kt * 4096);
                 sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
             }
+        }
         }
         // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
         const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
@@ -138,31 +157,35 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
             typedef __attribute__((ext_vector_type(2))) int i32x2;
             const unsigned va0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vbase[0];
             const unsigned va1 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)vbase[1];
-            i32x2 vr[2][4];   // [parity][i*2 + u]
-#define TR_ISSUE(par, step)                                                                                          \
+            i32x2 vr[3][4];   // [step % 3][i*2 + u]: transposing reads two steps ahead of their MFMAs
+#define TR_ISSUE(slot, step)                                                                                         \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int u = 0; u < 2; ++u)               \
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
-                             : "=v"(vr[par][i * 2 + u])                                                               \
+                             : "=v"(vr[slot][i * 2 + u])                                                              \
                              : "v"(i ? va1 : va0), "n"((((step) >> 1) * 32 + 16 * ((step) & 1) + 8 * u) * 128));
             TR_ISSUE(0, 0)
+            TR_ISSUE(1, 1)
 #pragma unroll
             for (int st = 0; st < 2 * NKT; ++st) {
-                const int kt = st >> 1, s2 = st & 1, par = st & 1;
+                const int kt = st >> 1, s2 = st & 1, slot = st % 3;
+                if (st + 2 < 2 * NKT) {
+                    if (slot == 0) { TR_ISSUE(2, st + 2) } else if (slot == 1) { TR_ISSUE(0, st + 2) } else { TR_ISSUE(1, st + 2) }
+                }
                 v8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                // DS operations return in order: everything but the 4 reads of each younger step has arrived
+                if (st + 2 < 2 * NKT) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (st + 1 < 2 * NKT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 v8 vf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     typedef __attribute__((ext_vector_type(4))) int i32x4;
                     i32x4 w;
-                    w[0] = vr[par][i * 2][0]; w[1] = vr[par][i * 2][1]; w[2] = vr[par][i * 2 + 1][0]; w[3] = vr[par][i * 2 + 1][1];
+                    w[0] = vr[slot][i * 2][0]; w[1] = vr[slot][i * 2][1]; w[2] = vr[slot][i * 2 + 1][0]; w[3] = vr[slot][i * 2 + 1][1];
                     vf[i] = __builtin_bit_cast(v8, w);
-                }
-                if (st + 1 < 2 * NKT) {
-                    if (par == 0) { TR_ISSUE(1, st + 1) } else { TR_ISSUE(0, st + 1) }
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i) o[i] = mfma_32x32x16(vf[i], pf, o[i]);
