@@ -8,7 +8,10 @@ freeze (``setup_cfg``, :145-166).  One process drives one GPU; under ``torchrun`
 RCCL and evaluation is sharded with an all-gather of logits (``leclip_amd.parallel``).  The data pipeline of the
 reference (Dassl datasets, sliding-window crops) is outside the hot path: without ``--root`` the evaluation runs on
 the deterministic synthetic image set with labels drawn from the scores themselves (a smoke run of the plumbing).
-Training (``forward_backward``) needs the text-tower backward kernels and is not built in this round.
+Without ``--eval-only`` the prompts are tuned first, the way the reference does it - on CAPTIONS fed through the text
+encoder in place of images (Caption_distill_double.py:338-352, 789-897): here the caption set is synthetic too, one
+templated sentence per (class, template) with that class as its label; ``OPTIM.MAX_EPOCH`` passes, the learning-rate
+schedule stepped per epoch, the prompt learner saved under ``--output-dir`` in the reference's checkpoint layout.
 """
 from __future__ import annotations
 
@@ -64,6 +67,43 @@ class _SyntheticLoader:
             yield {"img": img, "label": lab, "impath": [f"synthetic/{i}" for i in range(s, s + b)]}
 
 
+_TEMPLATES = ("a photo of a {}.", "there is a {} in the scene.", "a close-up photo of a {}.", "a picture showing a {}.")
+
+
+def synthetic_captions(classnames):
+    """(tokens [n, 77], one-hot labels [n, C]): one sentence per (class, template).  Without the BPE merge table (offline
+    image: only the prompts of clip/prompt_cache.json can be tokenised) the set shrinks to the cached template."""
+    from .clip import tokenize
+    names = [n.replace("_", " ") for n in classnames]
+    templates = _TEMPLATES
+    try:
+        caps = tokenize([t.format(n) for t in templates for n in names])
+    except FileNotFoundError:
+        templates = _TEMPLATES[:1]
+        caps = tokenize([t.format(n) for t in templates for n in names])
+    return caps, torch.eye(len(names)).repeat(len(templates), 1)
+
+
+def train_on_synthetic_captions(cfg, trainer, output_dir: str = ""):
+    """Prompt tuning on captions-as-images (reference forward_backward, CDD.py:789-897, run by dassl's epoch loop): one
+    templated sentence per (class, template), label = that class; batches of DATALOADER.TRAIN_X.BATCH_SIZE captions."""
+    caps, labels = synthetic_captions(trainer.classnames)
+    gen = torch.Generator().manual_seed(max(cfg.SEED, 0))
+    bs = int(cfg.DATALOADER.TRAIN_X.BATCH_SIZE)
+    trainer.build_optim()
+    last = {}
+    for epoch in range(int(cfg.OPTIM.MAX_EPOCH)):
+        order = torch.randperm(caps.shape[0], generator=gen)
+        for s in range(0, caps.shape[0], bs):
+            idx = order[s:s + bs]
+            last = trainer.forward_backward({"img": caps[idx], "label": labels[idx]})
+        trainer.update_lr()
+        print(f"epoch [{epoch + 1}/{cfg.OPTIM.MAX_EPOCH}] loss {last['loss']:.4f}")
+    if output_dir:
+        trainer.save_model(int(cfg.OPTIM.MAX_EPOCH), output_dir)
+    return last
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--root", type=str, default="", help="path to dataset")
@@ -90,8 +130,8 @@ def main(argv=None):
     evaluator = build_evaluator(cfg)
     trainer = build_trainer(cfg, evaluator=evaluator)
     trainer.load_model(args.model_dir, epoch=args.load_epoch)
-    if not args.eval_only:
-        raise NotImplementedError("training: the text-tower backward kernels are the next scope row (SURVEY.md §8f N1)")
+    if not args.eval_only and not args.no_train:
+        train_on_synthetic_captions(cfg, trainer, args.output_dir)
 
     res = cfg.INPUT.SIZE[0]
     loader = _SyntheticLoader(args.num_images, cfg.DATALOADER.TEST.BATCH_SIZE, res)

@@ -207,3 +207,16 @@ def test_trainer_momentum_copy_follows_the_prompts(ops, golden_dir):
     gap0 = float((m0 - model.prompt_learner.ctx.detach()).norm())
     gap1 = float((model.prompt_learner_m.ctx - model.prompt_learner.ctx.detach()).norm())
     assert gap1 < gap0 and not model.prompt_learner_m.ctx.requires_grad
+
+
+def test_train_caption_entry_point_tunes_saves_and_evaluates(ops, tmp_path):
+    """The reference's entry point end to end on the tiny model: caption-as-image prompt tuning for two epochs, checkpoint
+    in the reference layout, then the sharded evaluation with mAP."""
+    from leclip_amd import train_caption
+    torch.manual_seed(0)
+    out = train_caption.main(["--trainer", "Caption_distill_double", "--backbone", "tiny", "--output-dir", str(tmp_path), "--num-images", "64",
+                              "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)", "TRAINER.Caption.PREC", "fp32",
+                              "OPTIM.MAX_EPOCH", "2", "OPTIM.LR", "0.0002", "OPTIM.WARMUP_EPOCH", "0", "DATALOADER.TRAIN_X.BATCH_SIZE", "64",
+                              "DATALOADER.TEST.BATCH_SIZE", "32"])
+    assert (tmp_path / "default" / "model.pth.tar-2").exists()
+    assert out is not None and 0.0 <= float(out["mAP"]) <= 100.0

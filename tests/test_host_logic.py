@@ -247,3 +247,12 @@ def test_committed_bench_line_keeps_the_driver_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "img/s" and c["sample"]
     assert abs(d["value"] - d["n_gpus"] * 256 * d["steps"] / (d["ms_per_step"] * 1e-3 * d["steps"])) / d["value"] < 1e-6
+
+
+def test_synthetic_caption_set_for_the_entry_point():
+    """train_caption's caption-as-image training set: tokenised sentences with one-hot labels, built offline from the prompt cache."""
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.train_caption import synthetic_captions
+    caps, labels = synthetic_captions(coco_object_categories)
+    assert caps.shape[1] == 77 and caps.shape[0] == labels.shape[0] and caps.shape[0] % 80 == 0 and labels.shape[1] == 80
+    assert bool((labels.sum(1) == 1).all()) and int(caps[:, 0].min()) == 49406 and bool((caps.argmax(-1) > 2).all())
