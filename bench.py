@@ -42,7 +42,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="images per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16", "fp32"],
+                    help="compute dtype of the timed run.  Default fp16: the reference's own GPU precision (clip/model.py:470 "
+                         "convert_weights) and the dtype the north-star target names; it meets the +-0.2 mAP clause.  bf16 (BASELINE "
+                         "configs[1]'s wording) runs the same kernels at the same rate but misses that clause (8-bit mantissa): with the "
+                         "default dtype the bf16 rate and mAP are measured too and reported under \"bf16\" in the same JSON line")
+    ap.add_argument("--no-second-dtype", action="store_true", help="skip the bf16 companion measurement of the default run")
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph on the steps that are not profiled")
@@ -57,7 +62,6 @@ def main():
     if args.mode == "tune":
         return tune(args)
 
-    import numpy as np
     import torch
     import torch.distributed as dist
     from leclip_amd import parallel, synth
@@ -67,47 +71,19 @@ def main():
     from leclip_amd.hip import ops
     from leclip_amd.trainers import CustomCLIP
 
+    overrides = env_overrides()
     rank, world, local = parallel.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     dev = torch.device("cuda", torch.cuda.current_device())
     arch = synth.ARCHS[args.arch]
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-
+    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
     sd = synth.make_state_dict(arch, seed=0, dist="cond")
-    model = build_model(sd).float()
-    if dtype != torch.float32:
-        convert_weights(model, dtype)
-    cfg = get_cfg_default()
-    cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
-    cc = CustomCLIP(cfg, coco_object_categories, model)
     ctx = torch.from_numpy(synth.make_ctx(16, arch.transformer_width, seed=0))
-    with torch.no_grad():
-        cc.prompt_learner.ctx.copy_(ctx)
-    cc.to(dev).eval()
-
     B = args.batch
     images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(dev)
     streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
     parts = list(images.chunk(args.streams)) if streams else None
-
-    def score_fn(x):
-        if streams is None:
-            return cc(x, if_test=True)[0]
-        cur = torch.cuda.current_stream()
-        outs = []
-        for st, part in zip(streams, parts):
-            st.wait_stream(cur)
-            with torch.cuda.stream(st):
-                outs.append(cc(part, if_test=True)[0])
-        for st in streams:
-            cur.wait_stream(st)
-        return torch.cat(outs, dim=0)
-
-    scorer = parallel.ShardedScorer(score_fn)
-
-    def step():
-        return scorer.score_local(images)
 
     def fence():
         torch.cuda.synchronize()
@@ -115,39 +91,71 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        cc.class_text_features()          # text tower runs once; its features are cached for inference
-        for _ in range(args.warmup):
-            out = step()
-        fence()
-        graph = None
-        if args.graph and world == 1 and args.streams == 1:
-            # the ~105 launches of one step captured once (the C-ABI launches go to torch's current stream, which is the
-            # capturing stream here); replayed with one hipGraphLaunch per step
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                gout = step()
-            fence()
-        prof = []
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            # per-kernel HIP events on every `--profile-every`-th step of the timed region (a pair of event records around
-            # each launch costs a few microseconds of GPU idle; sampling keeps the measured rate honest)
-            sampled = args.profile_every > 0 and i % args.profile_every == 0
-            ops.set_profile(prof if sampled else None)
-            if graph is not None and not sampled:
-                graph.replay()
-                out = gout
-            else:
+    def build(dtype_name):
+        model = build_model(sd).float()
+        if DT[dtype_name] != torch.float32:
+            convert_weights(model, DT[dtype_name])
+        cfg = get_cfg_default()
+        cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+        cc = CustomCLIP(cfg, coco_object_categories, model)
+        with torch.no_grad():
+            cc.prompt_learner.ctx.copy_(ctx)
+        return cc.to(dev).eval()
+
+    def measure(cc, steps, warmup, profile_every):
+        """W untimed + exactly K timed steps of the hot path, bracketed by barrier + synchronize; max over ranks."""
+        def score_fn(x):
+            if streams is None:
+                return cc(x, if_test=True)[0]
+            cur = torch.cuda.current_stream()
+            outs = []
+            for st, part in zip(streams, parts):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    outs.append(cc(part, if_test=True)[0])
+            for st in streams:
+                cur.wait_stream(st)
+            return torch.cat(outs, dim=0)
+
+        scorer = parallel.ShardedScorer(score_fn)
+        step = lambda: scorer.score_local(images)
+        with torch.no_grad():
+            cc.class_text_features()          # text tower runs once; its features are cached for inference (SURVEY §8d)
+            for _ in range(warmup):
                 out = step()
-        ops.set_profile(None)
-        fence()
-        dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-    assert out.shape == (world * B, 80) and bool(torch.isfinite(out).all())
+            fence()
+            graph = None
+            if args.graph and world == 1 and args.streams == 1:
+                # the launches of one step captured once (the C-ABI launches go to torch's current stream, which is the
+                # capturing stream here); replayed with one hipGraphLaunch per step
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    gout = step()
+                fence()
+            prof = []
+            t0 = time.perf_counter()
+            for i in range(steps):
+                # per-kernel HIP events on every `profile_every`-th step of the timed region (a pair of event records around
+                # each launch costs a few microseconds of GPU idle; sampling keeps the measured rate honest)
+                sampled = profile_every > 0 and i % profile_every == 0
+                ops.set_profile(prof if sampled else None)
+                if graph is not None and not sampled:
+                    graph.replay()
+                    out = gout
+                else:
+                    out = step()
+            ops.set_profile(None)
+            fence()
+            dt = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        assert out.shape == (world * B, 80) and bool(torch.isfinite(out).all())
+        return dt, prof
+
+    cc = build(args.dtype)
+    dt, prof = measure(cc, args.steps, args.warmup, args.profile_every)
 
     # per-kernel-family durations from the HIP events recorded inside the timed region
     fam = {}
@@ -165,6 +173,7 @@ def main():
 
     ips = world * B * args.steps / dt
     fpi = flops_per_image(arch)
+    traffic, traffic_src = _pmc_traffic()
     result = {
         "metric": f"images/sec (multi-label forward, B={B}, {arch.image_resolution}x{arch.image_resolution})", "value": ips, "unit": "img/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
@@ -176,20 +185,49 @@ def main():
         "end_to_end_tflops_per_gpu": ips / world * fpi * 1e-12,
         "end_to_end_mfma_frac": ips / world * fpi * 1e-12 / PEAK_MFMA_TFLOPS,
         "roofline": {"bound": "mfma", "kernel": ops._capi.load().leclip_gemm_kernel_name(B * arch.vision_tokens, arch.vision_width,
-                                                                                         arch.vision_width, ops.dtype_code(dtype)).decode(),
+                                                                                         arch.vision_width, ops.dtype_code(DT[args.dtype])).decode(),
                      "achieved": gemm_tflops, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": gemm_tflops / PEAK_MFMA_TFLOPS, "traffic": _pmc_traffic(),
+                     "frac": gemm_tflops / PEAK_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src,
                      "flops_per_launch": g[1] / max(g[3], 1), "avg_launch_us": g[0] / max(g[3], 1) * 1e6},
         "kernels": kernels,
+        "env_overrides": overrides,
     }
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"], result["mAP"] = cpu_baseline(args, arch, sd, cc, ctx, dev)
+        result["cpu_baseline"], result["mAP"], ref_pack = cpu_baseline(args, arch, sd, cc, ctx, dev)
+        if not (abs(result["mAP"]["hip"] - result["mAP"]["oracle_fp32"]) <= 0.2):
+            result["mAP"]["accuracy_gate"] = f"MISSED: |mAP - oracle| > 0.2 in {args.dtype}"
+        else:
+            result["mAP"]["accuracy_gate"] = "met (|mAP - oracle| <= 0.2)"
+    else:
+        ref_pack = None
+    # Companion measurement: BASELINE configs[1] words the config as bf16.  Same kernels, same rate, but bf16 misses the
+    # north star's +-0.2 mAP clause, so it is not the headline: its rate and mAP sit beside the fp16 line.
+    if world == 1 and args.dtype == "fp16" and not args.no_second_dtype and args.streams == 1:
+        del cc
+        cc2 = build("bf16")
+        dt2, _ = measure(cc2, args.steps, max(2, args.warmup // 2), 0)
+        comp = {"value": B * args.steps / dt2, "unit": "img/s", "ms_per_step": dt2 / args.steps * 1e3, "steps": args.steps}
+        if ref_pack is not None:
+            comp["mAP"] = score_against(ref_pack, cc2, arch, dev)
+        result["bf16"] = comp
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def env_overrides():
+    """LECLIP_* variables in the environment.  The product library reads none of them (the timing / ablation hooks of round 1
+    now exist only in the diagnostic build, `make diag`); a run with LECLIP_GEMM_* / LECLIP_ATTN_* set is refused anyway so
+    that a profiling script's exports can never sit under a headline number.  LECLIP_HIP_LIB (library path) is recorded."""
+    found = sorted(k for k in os.environ if k.startswith("LECLIP_"))
+    bad = [k for k in found if k.startswith(("LECLIP_GEMM_", "LECLIP_ATTN_", "LECLIP_LN_"))]
+    if bad:
+        print(f"bench.py: refusing to run with kernel diagnostic switches in the environment: {bad}", file=sys.stderr)
+        sys.exit(2)
+    return [f"{k}={os.environ[k]}" for k in found]
 
 
 def tune(args):
@@ -226,16 +264,18 @@ def tune(args):
 
 
 def _pmc_traffic():
-    """HBM bytes per GEMM launch from the round's committed rocprofv3 --pmc pass (profiles/*_pmc_summary.json), or null."""
+    """HBM bytes per GEMM launch.  NOT measured by this process: rocprofv3 --pmc cannot run inside the timed run, so the
+    figure is read from the committed summary of the separate counter passes over this same command
+    (profiles/*_pmc_summary.json, newest round), and the source file is named next to it."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
     if not files:
-        return None
+        return None, None
     try:
         with open(files[-1]) as f:
-            return json.load(f).get("gemm_hbm_bytes_per_launch")
+            return json.load(f).get("gemm_hbm_bytes_per_launch"), "committed rocprofv3 --pmc passes: profiles/" + os.path.basename(files[-1])
     except Exception:
-        return None
+        return None, None
 
 
 def cpu_baseline(args, arch, sd, cc, ctx, dev):
@@ -280,23 +320,21 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
     m = {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(labels, ref), "hip": mAP(labels, hip),
          "max_abs_logit_diff": float(np.abs(ref - hip).max()),
          "top1_agree": float((ref.argmax(1) == hip.argmax(1)).mean())}
-    if args.dtype != "fp16":
-        # the reference's own GPU precision (clip.load keeps fp16 weights) on the same images: same kernels, same rate, 11-bit mantissa
-        from leclip_amd.clip import build_model
-        from leclip_amd.config import get_cfg_default
-        from leclip_amd.datasets import coco_object_categories
-        from leclip_amd.trainers import CustomCLIP
-        cfg = get_cfg_default()
-        cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
-        c16 = CustomCLIP(cfg, coco_object_categories, build_model(sd))      # build_model returns fp16 weights like the reference
-        with torch.no_grad():
-            c16.prompt_learner.ctx.copy_(ctx)
-            c16.to(dev).eval()
-            h16 = np.concatenate([c16(torch.from_numpy(synth.make_images(cb, arch.image_resolution, seed=4321, start=i * cb)).to(dev),
-                                      if_test=True)[0].float().cpu().numpy() for i in range(n)])
-        m["hip_fp16"] = mAP(labels, h16)
-        m["max_abs_logit_diff_fp16"] = float(np.abs(ref - h16).max())
-    return base, m
+    return base, m, {"ref": ref, "labels": labels, "n": n, "cb": cb}
+
+
+def score_against(pack, cc, arch, dev):
+    """mAP of another model (same weights, other dtype) on the images / labels / oracle logits of the cpu_baseline sample."""
+    import numpy as np
+    import torch
+    from leclip_amd import synth
+    from leclip_amd.evaluation import mAP
+    with torch.no_grad():
+        hip = np.concatenate([cc(torch.from_numpy(synth.make_images(pack["cb"], arch.image_resolution, seed=4321, start=i * pack["cb"])).to(dev),
+                                 if_test=True)[0].float().cpu().numpy() for i in range(pack["n"])])
+    ref = pack["ref"]
+    return {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(pack["labels"], ref), "hip": mAP(pack["labels"], hip),
+            "max_abs_logit_diff": float(np.abs(ref - hip).max()), "top1_agree": float((ref.argmax(1) == hip.argmax(1)).mean())}
 
 
 if __name__ == "__main__":

@@ -53,6 +53,7 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
 #pragma unroll
     for (int i = 0; i < 2; ++i)
         vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+    {
         const int qi = qb * 32 + fr;
         const int qrow = qi < a.T ? qi : a.T - 1;
         f32x16 sc[NKT];
@@ -205,6 +206,7 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                     *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
                 }
         }
+    }
 }
 
 template <typename T, int NKT>
@@ -550,21 +552,17 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a, int v_global)
 template <typename T>
 int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     const unsigned grid = (unsigned)(B * a.heads);
-    static const int force_pipe = [] { const char* e = getenv("LECLIP_ATTN_PIPE"); return e ? atoi(e) : -1; }();   // test hook
+#ifdef LECLIP_DIAG
+    static const int force_pipe = [] { const char* e = getenv("LECLIP_ATTN_PIPE"); return e ? atoi(e) : -1; }();   // A/B timing
+#else
+    constexpr int force_pipe = -1;
+#endif
     const bool pipe_ok = a.T > 192 && a.T <= 224;   // 7 query blocks for 8 waves
     if (pipe_ok && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
-        static int n_cu = 0;
-        static bool attr_set = false;
-        if (!n_cu) {
-            int dev = 0;
-            (void)hipGetDevice(&dev);
-            if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
-        }
+        const int n_cu = leclip_cu_count();
+        static bool attr_set[LECLIP_MAX_DEVICES] = {};
         constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_heads_kernel<T, 7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDSB);
-            attr_set = true;
-        }
+        leclip_set_max_lds(attn_heads_kernel<T, 7>, LDSB, attr_set);
         hipLaunchKernelGGL((attn_heads_kernel<T, 7>), dim3(grid < (unsigned)n_cu ? grid : (unsigned)n_cu), dim3(512), LDSB, s, a, (int)grid);
         return leclip_check_launch("attn_heads_kernel");
     }
@@ -573,11 +571,8 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     else if (a.T <= 224) hipLaunchKernelGGL((attn_rows_kernel<T, 7>), dim3(grid), dim3(256), 0, s, a);
     else if (a.T <= STREAM_TMAX) {
         const int TP = (a.T + 127) & ~127;
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_stream_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, STREAM_TMAX * 256);
-            attr_set = true;
-        }
+        static bool attr_set[LECLIP_MAX_DEVICES] = {};
+        leclip_set_max_lds(attn_stream_kernel<T>, STREAM_TMAX * 256, attr_set);
         hipLaunchKernelGGL((attn_stream_kernel<T>), dim3(grid), dim3(512), TP * 256, s, a, TP);
         return leclip_check_launch("attn_stream_kernel");
     } else {
@@ -611,11 +606,8 @@ extern "C" int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T
         const int TPAD = (T + 63) & ~63;
         const int v_global = T > F32_TMAX;
         const size_t lds = ((size_t)T * 65 * (v_global ? 1 : 2) + 4 * TPAD) * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)attn_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
+        static bool attr_set[LECLIP_MAX_DEVICES] = {};
+        leclip_set_max_lds(attn_f32_kernel, 160 * 1024, attr_set);
         hipLaunchKernelGGL(attn_f32_kernel, dim3((unsigned)(B * heads)), dim3(256), lds, s, a, v_global);
         return leclip_check_launch("attn_f32_kernel");
     }

@@ -234,11 +234,8 @@ template <typename T>
 int attn_bwd_launch(const void* qkv, const void* dout, void* dqkv, int64_t B, int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale,
                     int causal, hipStream_t s) {
     const size_t lds = ((size_t)4 * Tn * AB_LD + (size_t)Tn * (Tn + 1) + Tn) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)attn_bwd_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_set = true;
-    }
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(attn_bwd_kernel<T>, 160 * 1024, attr_set);
     hipLaunchKernelGGL((attn_bwd_kernel<T>), dim3((unsigned)(B * heads)), dim3(AB_THREADS), lds, s, (const T*)qkv, (const T*)dout, (T*)dqkv, Tn, heads,
                        ld_qkv, ld_out, scale, causal);
     return leclip_check_launch("attn_bwd_kernel");

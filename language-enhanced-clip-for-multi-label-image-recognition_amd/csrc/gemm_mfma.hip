@@ -1,7 +1,9 @@
 // Y = act(A . W^T + bias) + residual on the gfx950 matrix cores (bf16 / fp16 in, fp32 accumulate).
 //
 // Kernel "gemm_tn_128x128x64": one 256-thread workgroup (4 waves, 2x2) per 128x128 output tile, each wave a
-// 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16 accumulators.  A [M,K] and W [N,K] are both K-contiguous, so both
+// 64x64 sub-tile = 4x4 v_mfma_f32_16x16x32 accumulators - the SAME instruction, fed the same K sequence (32 k per MFMA,
+// ascending), as the 256x256 kernel (gemm_mfma256.hip), so both families produce bit-identical fp32 accumulators for a
+// given (row, column): which family a call takes depends on M, and an image's result must not depend on its batch.  A [M,K] and W [N,K] are both K-contiguous, so both
 // operand tiles are [128 rows][64 k] = 128-byte rows.  Tiles are staged HBM -> LDS with 16-byte LDS-DMA
 // (global_load_lds_dwordx4: no VGPR round trip), double buffered, one barrier per K-step.  The LDS image is
 // lane-linear per wave-instruction (8 rows x 128 B), so the bank-conflict swizzle is applied on the per-lane
@@ -10,7 +12,6 @@
 // Workgroup ids are remapped so that each XCD (blocks b, b+8, ...) walks a contiguous run of tiles, N fastest:
 // the A row-panel of a tile row is re-read from that XCD's L2, not from HBM.
 #include "leclip_common.h"
-#include <stdlib.h>
 
 namespace {
 
@@ -20,6 +21,10 @@ constexpr int STAGE_BYTES = 2 * TILE_BYTES;      // A + B
 constexpr int EPI_LD = 68;                       // floats per staged epilogue row (64 + 4 pad)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_LD * 4;  // one wave's 64x64 fp32 tile
 constexpr int LDS_BYTES = 4 * EPI_WAVE_BYTES;    // 68 KiB >= 2 * STAGE_BYTES (64 KiB): 2 workgroups per CU
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+__device__ __forceinline__ acc4 mfma16(bf16x8 a, bf16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ acc4 mfma16(f16x8 a, f16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
 
 struct GemmArgs {
     const void* A;
@@ -71,21 +76,22 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
     const T* A = (const T*)g.A;
     const T* W = (const T*)g.W;
 
-    f32x16 acc[2][2];
+    acc4 acc[4][4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
 
     const int nk = g.K / BK;
     stage_tile<T>(A, g.lda, m0, g.M, 0, smem, wave, lane);
     stage_tile<T>(W, g.ldw, n0, g.N, 0, smem + TILE_BYTES, wave, lane);
     __syncthreads();   // with LDS-DMA outstanding this is s_waitcnt vmcnt(0) + s_barrier
 
-    // per-lane fragment addressing: row r = lane&31 of a 32-row MFMA tile, k-chunk 2*kk + (lane>>5)
-    const int fr = lane & 31, fh = lane >> 5;
+    // per-lane fragment addressing (v_mfma_f32_16x16x32 operand map): row lane&15 of a 16-row tile, 16-byte k-chunk
+    // 4*kk + (lane>>4) of the 64-deep K-tile
+    const int fr = lane & 15, fc = lane >> 4;
     for (int t = 0; t < nk; ++t) {
         char* cur = smem + (t & 1) * STAGE_BYTES;
         if (t + 1 < nk) {
@@ -96,28 +102,28 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
         const char* sa = cur;
         const char* sb = cur + TILE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            v8 af[2], bfr[2];
+        for (int kk = 0; kk < 2; ++kk) {
+            v8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = wr * 64 + i * 32 + fr;
-                af[i] = *(const v8*)(sa + r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            for (int i = 0; i < 4; ++i) {
+                const int r = wr * 64 + i * 16 + fr;
+                af[i] = *(const v8*)(sa + r * 128 + (((4 * kk + fc) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int r = wc * 64 + j * 32 + fr;
-                bfr[j] = *(const v8*)(sb + r * 128 + (((2 * kk + fh) ^ ((r >> 1) & 7)) << 4));
+            for (int j = 0; j < 4; ++j) {
+                const int r = wc * 64 + j * 16 + fr;
+                bfr[j] = *(const v8*)(sb + r * 128 + (((4 * kk + fc) ^ ((r >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = mfma_32x32x16(af[i], bfr[j], acc[i][j]);
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(af[i], bfr[j], acc[i][j]);
         }
         __syncthreads();
     }
 
-    // ---- epilogue.  Accumulator (i,j) register r holds row (r&3) + 8*(r>>2) + 4*(lane>>5), column lane&31: a
-    // row-major store straight from registers would be 2-byte scalars in 64-byte runs.  Instead each wave parks its
+    // ---- epilogue.  Accumulator (i,j) register r holds row 16i + 4*(lane>>4) + r, column 16j + (lane&15): a
+    // row-major store straight from registers would be 2-byte scalars in 32-byte runs.  Instead each wave parks its
     // 64x64 fp32 tile in its own LDS region (the K-loop buffers are dead after the final barrier; rows padded to 68
     // floats so the column-per-lane ds_write_b32 are conflict-free), then re-reads it row-major, 8 columns per lane:
     // bias / QuickGELU / residual are applied on 8-wide chunks, residual and output move as 16-byte accesses, and
@@ -166,12 +172,12 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
     }
     // park the accumulators while those loads are in flight
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                st[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh) * EPI_LD + j * 32 + fr] = acc[i][j][r];
+            for (int r = 0; r < 4; ++r)
+                st[(i * 16 + 4 * fc + r) * EPI_LD + j * 16 + fr] = acc[i][j][r];
     if constexpr (PF != 3) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
@@ -200,11 +206,8 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_128x128x64(GemmArgs g) {
 
 template <typename T, int PF>
 int launch_mfma_pf(const GemmArgs& a, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_128x128x64<T, PF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(gemm_tn_128x128x64<T, PF>, LDS_BYTES, attr_set);
     hipLaunchKernelGGL((gemm_tn_128x128x64<T, PF>), dim3(a.tiles_total), dim3(256), LDS_BYTES, s, a);
     return leclip_check_launch("gemm_tn_128x128x64");
 }
@@ -248,28 +251,10 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
             return LECLIP_E_INVALID;
         }
     }
-    if (leclip_gemm256_eligible(M, N, K)) {
-        // Wave quantisation: the persistent 256x256 kernel runs whole rounds of n_cu tiles.  When the last round
-        // would be less than half full, the trailing tile rows go to the 128x128 kernel instead (2 workgroups per CU,
-        // finer tiles): e.g. N = 768 at M = 50432 is 591 tiles = 2.3 rounds -> 170 tile rows + 6912 rows.
-        const int n_cu = leclip_gemm256_cus();
-        const int64_t tile_rows = (M + 255) / 256, tn = N / 256, tiles = tile_rows * tn;
-        const int64_t rounds = tiles / n_cu, rem = tiles % n_cu;
-        const int64_t full_rows = rounds * n_cu / tn;
-        static const int split_min_k = [] { const char* e = getenv("LECLIP_GEMM_SPLIT_MINK"); return e ? atoi(e) : 0; }();
-        if (rounds >= 1 && rem > 0 && 2 * rem <= n_cu && !epi.rowmap_P && full_rows > 0 && full_rows * 256 < M && K >= split_min_k) {
-            const int64_t M1 = full_rows * 256;
-            int rc = leclip_gemm256_launch(A, W, M1, N, K, lda, ldw, epi, ab_dtype, s);
-            if (rc) return rc;
-            EpiParams e2 = epi;
-            e2.out = (char*)epi.out + M1 * epi.ldy * dtype_size(epi.out_dt);
-            if (epi.res) e2.res = (const char*)epi.res + M1 * epi.ldr * dtype_size(epi.res_dt);
-            if (epi.ln_stats) e2.ln_stats = epi.ln_stats + 2 * M1;
-            if (epi.stats_out) e2.stats_out = epi.stats_out + M1 * epi.stats_slots * 2;
-            return launch_128((const char*)A + M1 * lda * 2, W, M - M1, N, K, lda, ldw, e2, ab_dtype, s);
-        }
-        return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
-    }
+    // One kernel family per call, chosen from (M, N, K) alone and covering every row: an image's result must not depend on
+    // where its rows sit in the batch (round 1 sent the trailing tile rows of a large batch to the 128x128 kernel, whose
+    // MFMA shape sums K in a different order - sharded logits then differed from unsharded ones in the last bits).
+    if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     return launch_128(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
 }
 

@@ -71,9 +71,19 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
+// Timing / ablation hooks (skip the epilogue, the stores or the K-loop; start-up stagger; no cross-tile pipelining; strict
+// waits; grid cap; forced generic epilogue) exist only in the diagnostic library (make diag: -DLECLIP_DIAG, loaded by
+// leclip_kernel_check_diag, never by the package).  In the product build every one of them is the constant 0: the
+// shipped kernels have no mode that skips work and the library reads no environment variable.
+#ifdef LECLIP_DIAG
+#define DIAG(x) (x)
+#else
+#define DIAG(x) 0
+#endif
+
 // In-kernel timeline (diagnostic library build only; the shipped kernel contains no stamp): wave 0 / lane 0 of every
 // workgroup records the shader clock at five points of each tile.
-#ifdef LECLIP_GEMM_STAMPS
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
 #define STAMP(k)                                                                                              \
     do {                                                                                                      \
         if (g.stamps && wave == 0 && lane == 0 && tile_it < 16)                                               \
@@ -214,7 +224,7 @@ __device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[
     if constexpr (PF == 2) {
         const float mean = ln_val[0], rstd = ln_val[1];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, v[c] - mean * s8[c], b8[c]);
+        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, fmaf(-mean, s8[c], v[c]), b8[c]);
     } else {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] += b8[c];
@@ -310,10 +320,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     // tile's epilogue.  Either way K-tile 0 (+ K-tile 1's k0 slots) of the next tile is in LDS or in flight while the
     // epilogue stages through the remaining 64 KiB.
     // LECLIP_GEMM_DESYNC (diagnostic, measured to make no difference - DESIGN.md §6): start groups of workgroups late.
-    if (g.desync) {
-        const int groups = g.desync >> 8 ? g.desync >> 8 : 4;            // desync = groups * 256 + step (step in ~512-cycle units)
+    if (DIAG(g.desync)) {
+        const int groups = DIAG(g.desync) >> 8 ? DIAG(g.desync) >> 8 : 4;            // desync = groups * 256 + step (step in ~512-cycle units)
         const int phi = (blockIdx.x >> 3) % groups;
-        for (int i = 0; i < phi * (g.desync & 255); ++i) __builtin_amdgcn_s_sleep(8);
+        for (int i = 0; i < phi * (DIAG(g.desync) & 255); ++i) __builtin_amdgcn_s_sleep(8);
     }
     int v = blockIdx.x;
     int64_t m0;
@@ -322,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     set_sources(m0, n0);
     prologue();
     // Cross-tile pipelining (see PP::ktile): an even number of K-tiles keeps the stage parity across the tile boundary.
-    const bool pipelined = (nk & 1) == 0 && !(g.dbg & 4) && !g.no_xtile;
+    const bool pipelined = (nk & 1) == 0 && !(DIAG(g.dbg) & 4) && !DIAG(g.no_xtile);
     // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 16 partial-sum pairs)
     // (+ the 8 loads of the second residual batch, which are younger than the next tile's prologue DMA as well)
     constexpr int EPI_STORES = CFG >= 0 ? 16 * (1 + ((CFG >> 1) & 1)) + (PF == 1 ? 8 : 0) : 0;
@@ -359,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (nx) tile_origin(vn, m0n, n0n);
         auto next_src = [&] { set_sources(m0n, n0n); };
         int t = 0;
-        if (g.dbg & 4) t = nk - 2 > 0 ? nk - 2 : 0;
+        if (DIAG(g.dbg) & 4) t = nk - 2 > 0 ? nk - 2 : 0;
         for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
         p.template ktile<1, EPI_STORES>(t, nx, next_src);
 
@@ -505,7 +515,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             typedef typename VecOf<T>::v4 v4t;
             typedef typename VecOf<T>::v8 v8t;
             drain = true;
-            if (!(g.dbg & 1)) {
+            if (!(DIAG(g.dbg) & 1)) {
                 constexpr int PITCH = 136, STRIP = 16 * PITCH;
                 char* st = smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES);
                 auto park16 = [&](int q) {
@@ -526,7 +536,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             float v = p.acc[q >> 2][q & 3][j][r];
-                            if constexpr (PF == 2) v = fmaf(rstd, v - mean * s16[4 * j + r], b16[4 * j + r]);
+                            if constexpr (PF == 2) v = fmaf(rstd, fmaf(-mean, s16[4 * j + r], v), b16[4 * j + r]);
                             else v += b16[4 * j + r];
                             if constexpr (ACT == 1) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
                             w[r] = (T)v;
@@ -558,8 +568,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                         }
                     }
                 };
-                if (g.dbg & 2) passes16(BoolC<true>{}, BoolC<true>{});
-                else if (em0 + TM <= g.M) { passes16(BoolC<false>{}, BoolC<false>{}); drain = g.strict_wait != 0; }
+                if (DIAG(g.dbg) & 2) passes16(BoolC<true>{}, BoolC<true>{});
+                else if (em0 + TM <= g.M) { passes16(BoolC<false>{}, BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
                 else passes16(BoolC<true>{}, BoolC<false>{});
             } else if (p.acc[0][0][0][0] == 12345.678f) {
                 ((float*)e.out)[0] = 1.f;
@@ -570,7 +580,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             // the other's arithmetic and stores).  The 64 KiB come from the epilogue region plus the k1 slots of
             // stage 1, which the next tile's prologue does not touch.
             drain = true;
-            if (!(g.dbg & 1)) {
+            if (!(DIAG(g.dbg) & 1)) {
                 constexpr int ACT = CFG & 1, STATS = (CFG >> 1) & 1;
                 float* st = (float*)(smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES));
                 const int wsw = ((lane_e >> 4) & 1) << 4;
@@ -633,14 +643,14 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                         }
                     }
                 };
-                if (g.dbg & 2) passes(BoolC<true>{}, BoolC<true>{});
-                else if (em0 + TM <= g.M) { passes(BoolC<false>{}, BoolC<false>{}); drain = g.strict_wait != 0; }
+                if (DIAG(g.dbg) & 2) passes(BoolC<true>{}, BoolC<true>{});
+                else if (em0 + TM <= g.M) { passes(BoolC<false>{}, BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
                 else passes(BoolC<true>{}, BoolC<false>{});
             } else if (p.acc[0][0][0][0] == 12345.678f) {
                 ((float*)e.out)[0] = 1.f;
             }
         } else
-        if (!(g.dbg & 1)) {
+        if (!(DIAG(g.dbg) & 1)) {
             float* st = (float*)(smem + 2 * STAGE_BYTES + wave * EPI_WAVE_BYTES);
             const int wsw = ((lane >> 4) & 1) << 4;
 #pragma unroll
@@ -661,7 +671,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                     float vv[8];
 #pragma unroll
                     for (int c = 0; c < 4; ++c) { vv[c] = v0[c]; vv[4 + c] = v1[c]; }
-                    if ((g.dbg & 2) && vv[0] != 12345.678f) continue;
+                    if ((DIAG(g.dbg) & 2) && vv[0] != 12345.678f) continue;
                     epi_chunk8<PF>(e, m, n, vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], lnpre[0]);   // (generic code is only instantiated for PF == 3)
                 }
             }
@@ -677,11 +687,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 
 template <typename T, int PF, int CFG>
 int launch256_pf(const Gemm256Args& a, int grid, hipStream_t s) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_tn_256x256x64_pp<T, PF, CFG>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        attr_set = true;
-    }
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(gemm_tn_256x256x64_pp<T, PF, CFG>, LDS_BYTES, attr_set);
     hipLaunchKernelGGL((gemm_tn_256x256x64_pp<T, PF, CFG>), dim3(grid), dim3(512), LDS_BYTES, s, a);
     return leclip_check_launch("gemm_tn_256x256x64_pp");
 }
@@ -689,8 +696,12 @@ int launch256_pf(const Gemm256Args& a, int grid, hipStream_t s) {
 template <typename T>
 int launch256(const Gemm256Args& a, hipStream_t s) {
     const int n_cu = leclip_gemm256_cus();
-    static const int cap = [] { const char* e = getenv("LECLIP_GEMM_GRID"); return e ? atoi(e) : 0; }();   // test hook: force multi-tile loops
+#ifdef LECLIP_DIAG
+    static const int cap = [] { const char* e = getenv("LECLIP_GEMM_GRID"); return e ? atoi(e) : 0; }();   // force multi-tile loops
     static const int force_generic = [] { const char* e = getenv("LECLIP_GEMM_EPI"); return e && !strcmp(e, "generic") ? 1 : 0; }();
+#else
+    constexpr int cap = 0, force_generic = 0;
+#endif
     const int limit = cap > 0 ? cap : n_cu;
     const int grid = a.tiles_total < limit ? a.tiles_total : limit;   // one persistent workgroup per CU (160 KiB LDS each)
     const EpiParams& e = a.epi;
@@ -708,27 +719,32 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 
 }  // namespace
 
+#ifdef LECLIP_DIAG
 static unsigned long long* g_stamps = nullptr;
-// diagnostic hook (kernel_check --stamps, library built with -DLECLIP_GEMM_STAMPS): device buffer for the in-kernel timeline
+// diagnostic library only (make diag): device buffer for the in-kernel timeline
 extern "C" void leclip_gemm256_set_stamps(unsigned long long* device_buf) { g_stamps = device_buf; }
+#endif
 
-int leclip_gemm256_cus() {
-    static int n_cu = 0;
-    if (!n_cu) {
-        int dev = 0;
-        (void)hipGetDevice(&dev);
-        if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu <= 0) n_cu = 256;
+int leclip_cu_count() {
+    static int n_cu[LECLIP_MAX_DEVICES] = {};
+    const int dev = leclip_device_ordinal();
+    if (!n_cu[dev]) {
+        int v = 0;
+        n_cu[dev] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
     }
-    return n_cu;
+    return n_cu[dev];
 }
+int leclip_gemm256_cus() { return leclip_cu_count(); }
 
 // Shapes this kernel takes: N % 256 == 0, K % 64 == 0, K >= 128; worth it only when the grid fills the chip.
 bool leclip_gemm256_eligible(int64_t M, int N, int K) {
     if (N % TN != 0 || K % TK != 0 || K < 2 * TK) return false;
-    // LECLIP_GEMM_TILE=256 / 128 forces a kernel family (tests, A/B timing); unset = heuristic below
+#ifdef LECLIP_DIAG
+    // LECLIP_GEMM_TILE=256 / 128 forces a kernel family (A/B timing); unset = heuristic below
     static const int forced = [] { const char* e = getenv("LECLIP_GEMM_TILE"); return e ? atoi(e) : 0; }();
     if (forced == 256) return true;
     if (forced == 128) return false;
+#endif
     const int64_t tiles = ((M + TM - 1) / TM) * (N / TN);
     return tiles >= 192;
 }
@@ -741,6 +757,9 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.tiles_n = N / TN;
     if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
     a.tiles_total = (int)(tiles_m * a.tiles_n);
+    a.dbg = a.desync = a.no_xtile = a.strict_wait = 0;
+    a.stamps = nullptr;
+#ifdef LECLIP_DIAG
     static const int dbg = [] { const char* e = getenv("LECLIP_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
     a.dbg = dbg;
     static const int desync = [] { const char* e = getenv("LECLIP_GEMM_DESYNC"); return e ? atoi(e) : 0; }();
@@ -750,5 +769,6 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.no_xtile = no_xtile;
     static const int strict_wait = [] { const char* e = getenv("LECLIP_GEMM_STRICT_WAIT"); return e ? atoi(e) : 0; }();
     a.strict_wait = strict_wait;
+#endif
     return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
 }

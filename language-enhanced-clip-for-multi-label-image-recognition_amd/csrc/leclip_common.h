@@ -70,6 +70,24 @@ static inline bool dtype_ok(int dt) { return dt == LECLIP_F32 || dt == LECLIP_F1
 void leclip_set_error(const char* fmt, ...);
 int leclip_check_launch(const char* what);
 
+// Per-device one-time function attributes (max dynamic LDS) and the CU count: hipFuncSetAttribute applies to the current
+// device only, so the "already done" state is kept per device ordinal, not per process.
+constexpr int LECLIP_MAX_DEVICES = 64;
+static inline int leclip_device_ordinal() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return dev >= 0 && dev < LECLIP_MAX_DEVICES ? dev : 0;
+}
+template <typename F>
+static inline void leclip_set_max_lds(F* kernel, int bytes, bool (&done)[LECLIP_MAX_DEVICES]) {
+    const int dev = leclip_device_ordinal();
+    if (!done[dev]) {
+        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        done[dev] = true;
+    }
+}
+int leclip_cu_count();   // CUs of the current device (gemm_mfma256.hip)
+
 // Epilogue description shared by the GEMM kernels.
 struct EpiParams {
     const float* bias;   // [N] or null
@@ -105,7 +123,7 @@ __device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n,
         const f32x2 st = have_ln ? ln_val : *(const f32x2*)(e.ln_stats + 2 * m);
         const float mean = st[0], rstd = st[1];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, v[c] - mean * s8[c], b8[c]);
+        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, fmaf(-mean, s8[c], v[c]), b8[c]);
     } else {
 #pragma unroll
         for (int c = 0; c < 8; ++c) v[c] += b8[c];

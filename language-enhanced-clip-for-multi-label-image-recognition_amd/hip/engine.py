@@ -24,12 +24,6 @@ from . import ops
 from ._capi import ACT_NONE, ACT_QUICKGELU
 
 
-import os
-
-# where the fused LayerNorm's row statistics come from: "epilogue" (partial sums written by the producing GEMM) or
-# "kernel" (a read-only pass over the residual stream)
-_LN_STATS_MODE = os.environ.get("LECLIP_LN_STATS", "epilogue")
-
 
 def _f32(t: torch.Tensor, device) -> torch.Tensor:
     return t.detach().to(device=device, dtype=torch.float32).contiguous()
@@ -89,7 +83,7 @@ class _Workspace:
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
-               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None) -> torch.Tensor:
+               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, epilogue_stats: bool = True) -> torch.Tensor:
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
@@ -102,7 +96,8 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
     if fuse_ln:
         ops.row_stats(x, out=ws.stats)
         last = len(blocks) - 1
-        epilogue_stats = _LN_STATS_MODE == "epilogue"
+        # epilogue_stats: the fused LayerNorm's row statistics come from partial sums written by the producing GEMM's
+        # epilogue (default); False = a read-only pass over the residual stream (kept as a cross-check for tests)
         for i, p in enumerate(blocks):
             ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_stats=ws.stats, ln_colsum=p.cs_qkv, out=ws.qkv)
             ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)

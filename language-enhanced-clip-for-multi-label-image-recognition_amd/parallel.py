@@ -56,15 +56,16 @@ def all_gather_rows(local: torch.Tensor, counts=None) -> torch.Tensor:
 
 
 def _gather_flat(block: torch.Tensor, world: int) -> torch.Tensor:
-    """Equal-size blocks -> one [world * n, ...] tensor in rank order.  RCCL: a single all_gather_into_tensor on one flat
-    buffer; backends without that primitive for this device (gloo with device tensors) use the list form."""
-    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
-    try:
-        dist.all_gather_into_tensor(out, block)
-    except (RuntimeError, NotImplementedError):
+    """Equal-size blocks -> one [world * n, ...] tensor in rank order.  RCCL ("nccl"): a single all_gather_into_tensor on
+    one flat buffer - an error there is a real communicator failure and propagates.  gloo (the CPU test transport, also
+    used to carry device tensors when two test ranks share one GPU) has no flat primitive: list form, chosen by backend
+    name, never by catching an exception."""
+    if dist.get_backend() == "gloo":
         parts = [torch.empty_like(block) for _ in range(world)]
         dist.all_gather(parts, block)
-        out = torch.cat(parts, dim=0)
+        return torch.cat(parts, dim=0)
+    out = torch.empty((world * block.shape[0],) + tuple(block.shape[1:]), dtype=block.dtype, device=block.device)
+    dist.all_gather_into_tensor(out, block)
     return out
 
 

@@ -144,7 +144,7 @@ def test_gemm_inplace_residual_and_errors(ops):
 def test_gemm256_specialised_epilogues(ops, dt, shape):
     """Shapes with >= 192 tiles of 256x256 run the persistent kernel; each of its compile-time epilogues (bias, +QuickGELU,
     +residual, +residual+LayerNorm partial sums, fused LayerNorm, fused LayerNorm+QuickGELU) against fp32 torch on the
-    device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a wave-quantisation tail on the 128 kernel;
+    device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a third round that fills a third of the CUs;
     K = 320 has an odd number of K-tiles (no cross-tile pipelining: prologue between tiles), K = 128 the minimum of two."""
     M, N, K = shape
     g = torch.Generator(device="cpu").manual_seed(7)
@@ -174,6 +174,46 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
     assert float((part[..., 0] - yy.sum(-1)).abs().max()) <= 1e-3 and float((part[..., 1] - (yy * yy).sum(-1)).abs().max()) <= 2e-2
     check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum), lnref)
     check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=ops.ACT_QUICKGELU), gelu(lnref))
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_families_are_bit_identical(ops, dt):
+    """Which GEMM kernel family a call takes depends on M (256x256 persistent kernel when the grid fills the chip, 128x128
+    otherwise).  Both feed v_mfma_f32_16x16x32 the same ascending K sequence and share the epilogue arithmetic, so a
+    row's result is the same bits in a large batch and in a small one - the property behind shard / batch invariance of
+    the logits.  Every epilogue flavour: plain, +bias+QuickGELU, +residual (+LayerNorm partial sums), fused LayerNorm
+    (+QuickGELU), 16-bit and fp32 output."""
+    lib = ops._capi.load()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    for (M, N, K) in ((50432, 768, 768), (30000, 2304, 768), (20000, 768, 3072)):
+        ms = 197 * 3 + 5
+        assert lib.leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)) == b"gemm_tn_256x256x64_pp"
+        assert lib.leclip_gemm_kernel_name(ms, N, K, ops.dtype_code(dt)) == b"gemm_tn_128x128x64"
+        a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = torch.randn(M, N, generator=g).to(dt).to(DEV)
+        stats = torch.stack([torch.randn(M, generator=g) * 0.1, torch.rand(M, generator=g) + 0.5], dim=1).contiguous().to(DEV)
+        colsum = torch.randn(N, generator=g).to(DEV)
+        lo = slice(M - ms, M)       # the LAST rows of the big call (ragged edge tile of the 256 kernel) vs a small call on them
+        sa, sres, sstats = a[lo].contiguous(), res[lo].contiguous(), stats[lo].contiguous()
+        cases = [
+            (dict(), dict()),
+            (dict(bias=bias, act=ops.ACT_QUICKGELU), dict(bias=bias, act=ops.ACT_QUICKGELU)),
+            (dict(bias=bias, residual=res), dict(bias=bias, residual=sres)),
+            (dict(bias=bias, out_dtype=torch.float32), dict(bias=bias, out_dtype=torch.float32)),
+        ]
+        for kb, ks in cases:
+            assert torch.equal(ops.gemm(a, w, **kb)[lo], ops.gemm(sa, w, **ks))
+        pb, ps = torch.zeros(M, N // 64, 2, device=DEV), torch.zeros(ms, N // 64, 2, device=DEV)
+        yb = ops.gemm_ln(a, w, bias, residual=res, stats_out=pb)
+        ys = ops.gemm_ln(sa, w, bias, residual=sres, stats_out=ps)
+        assert torch.equal(yb[lo], ys) and torch.equal(pb[lo], ps)
+        for act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
+            yb = ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=act)
+            ys = ops.gemm_ln(sa, w, bias, ln_stats=sstats, ln_colsum=colsum, act=act)
+            assert torch.equal(yb[lo], ys)
+        del a, w, res
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -364,15 +404,19 @@ def test_custom_clip_golden(ops, golden_dir, dt):
     assert torch.equal(prompts.cpu(), want)
 
 
-def test_full_batch_properties(ops):
-    """BASELINE config 2 size (B=256, bf16).  Size-independent properties: run-to-run determinism (bit for bit),
-    batch invariance - an image's logits do not depend on which batch or shard it is scored in (rows may take a
-    different GEMM kernel family when M changes - 256x256 ping-pong, its 128x128 tail, or 128x128 alone - so equality is
-    up to fp32 summation order: well inside the bf16 band, same top-1) - and the cosine bound |logit| <= 4."""
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_full_batch_properties(ops, dt):
+    """BASELINE config 2 size (B=256).  Size-independent properties: run-to-run determinism (bit for bit); SHARD
+    INVARIANCE, bit for bit - an image's logits do not depend on which shard of the batch it is scored in (cfg 4: the
+    all-gathered logits of 2 / 4 ranks' shards equal the single-GPU run: every GEMM of a call runs ONE kernel family
+    whose per-row arithmetic is independent of the row's position, attention is per (image, head), LayerNorm statistics
+    are per row with a fixed summation order); BATCH INVARIANCE - a single image (M = 197 rows: the 128x128 GEMM
+    family, the non-pipelined attention kernel) gives the same bits as that image inside the batch of 256, because both
+    GEMM families accumulate with the same MFMA in the same K order; and the cosine bound |logit| <= 4."""
     from leclip_amd.config import get_cfg_default
     from leclip_amd.datasets import coco_object_categories
     from leclip_amd.trainers import CustomCLIP
-    m = _build(synth.VIT_B16, 0, "cond", torch.bfloat16).cpu()
+    m = _build(synth.VIT_B16, 0, "cond", dt).cpu()
     cc = CustomCLIP(get_cfg_default(), coco_object_categories, m).to(DEV).eval()
     img = torch.from_numpy(synth.make_images(256, 224, seed=77)).to(DEV)
     with torch.no_grad():
@@ -380,23 +424,22 @@ def test_full_batch_properties(ops):
         again = cc(img, if_test=True)[0].clone()
         lo = cc(img[:128].contiguous(), if_test=True)[0].clone()
         hi = cc(img[128:].contiguous(), if_test=True)[0].clone()
+        ragged = torch.cat([cc(img[a:b].contiguous(), if_test=True)[0] for a, b in ((0, 100), (100, 187), (187, 256))])
         one = cc(img[200:201].contiguous(), if_test=True)[0].clone()
     assert torch.isfinite(full).all() and torch.equal(full, again)
-    shards = torch.cat([lo, hi])
-    assert float((full - shards).abs().max()) < 3e-2
-    assert float((full[200:201] - one).abs().max()) < 3e-2
-    band = float((full - shards).abs().max())
-    s2 = torch.sort(full, dim=1).values
-    clear = (s2[:, -1] - s2[:, -2]) > 2 * band      # top-1 margin above twice the observed summation-order noise
-    assert torch.equal(full.argmax(1)[clear], shards.argmax(1)[clear]) and int(clear.sum()) > 128
+    assert torch.equal(full[:128], lo) and torch.equal(full[128:], hi)      # 2 equal shards == unsharded, bit for bit
+    assert torch.equal(full, ragged)                                        # ragged shards (100 / 87 / 69 images) too
+    assert torch.equal(full[200:201], one)                                  # B = 1 == the same image inside B = 256
     assert float(full.abs().max()) <= 4.0 + 1e-4   # |cos| <= 1 scaled by 4
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 1.0)])
+@pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 0.6)])
 def test_map_against_oracle(ops, dt, tol):
     """mAP over 80 labels of the HIP logits vs the fp32 CPU oracle's on the same 256 images, labels drawn from the
-    oracle logits (north-star: within +-0.2; met in fp16 - bf16's 8-bit mantissa moves near-tied image ranks, its
-    measured gap is reported by bench.py and bounded here)."""
+    oracle logits.  North star: within +-0.2 - met by fp16, the reference's own GPU precision (model.py:470) and the
+    headline dtype of bench.py (measured 0.004 .. 0.03).  bf16 is bounded at what it achieves (measured 0.35 .. 0.43):
+    profiles/r02_lowprec_error_budget.py shows the gap is the 8-bit mantissa of the ACTIVATIONS themselves (any bf16
+    run of the reference would carry it; an fp32 residual stream only recovers a third of it), not an implementation loss."""
     from leclip_amd.config import get_cfg_default
     from leclip_amd.datasets import coco_object_categories
     from leclip_amd.evaluation import mAP
