@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 2
+#define LECLIP_ABI_VERSION 3
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -66,9 +66,10 @@ int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias
  *      Y = act(rstd[m] * (x . W'^T - mean[m] * ln_colsum[n]) + bias[n]) + residual,
  *    with ln_stats [M][2] = (mean, rstd) per row, ln_colsum[n] = sum_k W'[n,k], bias[n] = sum_k beta[k] W[n,k] + b[n]:
  *    algebraically clip/model.py:193-199 followed by F.linear, without materialising (or 16-bit rounding) LN(x).
- *  - stats_out != NULL: additionally writes, per output row and 64-column block, (sum, sum of squares) of the rounded
- *    outputs to stats_out [M][N/64][2]; leclip_ln_stats_finalize_fwd turns them into (mean, rstd) for the next
- *    fused GEMM.  Plain stores in a fixed layout: deterministic, nothing to zero. */
+ *  - stats_out != NULL: additionally writes, per output row and 64-column block, (sum, sum of squared deviations from
+ *    the block mean) of the rounded outputs to stats_out [M][N/64][2]; leclip_ln_stats_finalize_fwd merges the blocks
+ *    (parallel-variance update) into (mean, rstd) for the next fused GEMM.  Plain stores in a fixed layout:
+ *    deterministic, nothing to zero, no E[x^2] - mean^2 cancellation on rows with |mean| >> std. */
 int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
                              const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M, int N,
                              int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
@@ -133,6 +134,45 @@ int leclip_add_pos_fwd(const float* in, const float* pos, void* x, int64_t n, in
 /* Index of the maximum token id per row (first occurrence), = tokens.argmax(-1) (clip/model.py:390), plus the flat
  * row n*T + argmax used by leclip_gather_ln_proj_fwd. */
 int leclip_eot_index_fwd(const int64_t* tokens, int64_t* eot, int64_t* flat_row, int64_t n, int T, void* stream);
+
+/* The whole tail of the image branch in one launch, both contractions on the matrix cores:
+ *   feat[b, :] = LayerNorm(x[b * row_stride : +dim]) @ proj          (clip/model.py:271-274: ln_post(x[:, 0, :]) @ proj)
+ *   logits[b, c] = scale * <feat_b / |feat_b|, txt_c / |txt_c|>      (model.py:399-404; Caption_distill_double.py:330-335)
+ * x in `dtype` (class-token row of image b at element offset b * row_stride), proj_t [E, dim] = proj^T in `dtype`
+ * (K contiguous), txt [C, E] fp32 un-normalised text features.  feat [B, E] fp32 and logits [B, C] fp32 are each optional
+ * (NULL), at least one must be given.  16-bit dtypes: v_mfma_f32_16x16x32 for the projection; fp32: the exact
+ * v_mfma_f32_16x16x4_f32; the logit contraction always runs in exact fp32 MFMA on the unrounded features.
+ * dim % 64 == 0, dim <= 1024, E % 16 == 0. */
+int leclip_image_tail_fwd(const void* x, const float* gamma, const float* beta, const void* proj_t, const float* txt,
+                          float* feat, float* logits, int64_t B, int64_t row_stride, int dim, int E, int C, float eps,
+                          float scale, leclip_dtype dtype, void* stream);
+
+/* Gradient of leclip_l2norm_logits_fwd w.r.t. the text features (image features are frozen, reference :762-765):
+ * dtxt [C, D] from dlogits [B, C]; all fp32; D <= 1024. */
+int leclip_l2norm_logits_bwd(const float* img, const float* txt, const float* dlogits, float* dtxt, int64_t B, int C, int D,
+                             float scale, void* stream);
+
+/* dst[i, :] = src[index[i], :] (n rows)  and  dst = 0; dst[index[i], :] = src[i, :] (n rows into dst_rows rows; indices
+ * distinct).  The EOT-row gather / scatter around ln_final in the prompt-tuning backward (model.py:390). Rows of
+ * dim elements, leading dimensions in elements, row bytes a multiple of 16. */
+int leclip_gather_rows_fwd(const void* src, const int64_t* index, void* dst, int64_t n, int dim, int64_t ld_src, int64_t ld_dst,
+                           leclip_dtype dtype, void* stream);
+int leclip_scatter_rows_fwd(const void* src, const int64_t* index, void* dst, int64_t n, int64_t dst_rows, int dim, int64_t ld_src,
+                            int64_t ld_dst, leclip_dtype dtype, void* stream);
+
+/* Multi-crop test path: every window of every image through the reference's test transform, on the device.
+ * Replaces `tfm(F.to_pil_image(block))` per window in DatasetWrapperWithBlock._transform_image
+ * (dassl/data/data_manager.py:392-399, 417-425, ...) with tfm = Resize(S, bicubic) on the smaller edge + CenterCrop(S) +
+ * ToTensor + Normalize (dassl/data/transforms/transforms.py:379-400).  The resize reproduces Pillow's 8-bit resampler
+ * (libImaging/Resample.c: double-precision bicubic coefficients, 22-bit fixed point, horizontal pass then vertical pass)
+ * bit for bit; the size rule is torchvision 0.12's.
+ * src uint8 [B, 3, H, W] (planar); windows int32 [NW, 5] on the DEVICE = (y0, x0, rows, cols, pad_top): rows are counted on
+ * the image after pad_top reflected rows were put on top (reflection also below the last row), columns are not padded;
+ * the same NW windows are cut from each of the B images.  out [B, NW, 3, S, S] in out_dtype.  mean3 / std3: HOST pointers to
+ * the three Normalize constants.  Windows are validated by the caller (rows / S and cols / S <= 15.5); the kernel clamps
+ * every index, so a malformed window cannot fault. */
+int leclip_crop_resize_fwd(const uint8_t* src, int64_t B, int H, int W, const int32_t* windows, int NW, void* out, int S,
+                           const float* mean3, const float* std3, leclip_dtype out_dtype, void* stream);
 
 /* ---- score post-processing of the reference's test loop
  * Sliding-window aggregation, trainers/Caption_distill_double.py:654-660: window_logits [B, W, C] are the scores of the W

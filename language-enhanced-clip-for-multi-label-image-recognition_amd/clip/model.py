@@ -151,6 +151,13 @@ class VisionTransformer(nn.Module):
             raise RuntimeError("VisionTransformer.forward needs a HIP device tensor (no CPU fallback on the product path)")
         return self.engine(x.device).forward(x, taps)
 
+    def score(self, x: torch.Tensor, text_features: torch.Tensor, scale: float) -> torch.Tensor:
+        """scale * normalize(self(x)) @ normalize(text_features).T (model.py:399-404) with the contraction folded into the
+        tower's tail kernel: logits [B, C] fp32."""
+        if not x.is_cuda:
+            raise RuntimeError("VisionTransformer.score needs a HIP device tensor (no CPU fallback on the product path)")
+        return self.engine(x.device).score(x, text_features, scale)[1]
+
 
 class CLIP(nn.Module):
     def __init__(self, embed_dim: int, image_resolution: int, vision_layers, vision_width: int, vision_patch_size: int,

@@ -243,14 +243,20 @@ __device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[
     for (int c = 0; c < 8; ++c) o8[c] = (T)v[c];
     *(v8*)optr = o8;
     if constexpr (STATS == 1) {
-        float s1 = 0.f, s2 = 0.f;
+        // (sum, centred sum of squares) of the 64-column block: M2 about the BLOCK mean, so that a large common offset of the
+        // row never enters a difference of two large sums (the consumer merges the blocks with the parallel-variance update)
+        float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { const float r = (float)o8[c]; s1 += r; s2 = fmaf(r, r, s2); }
+        for (int c = 0; c < 8; ++c) s1 += (float)o8[c];
         s1 = row8_sum(s1);
-        s2 = row8_sum(s2);
+        const float mb = s1 * (1.0f / 64.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float dlt = (float)o8[c] - mb; m2 = fmaf(dlt, dlt, m2); }
+        m2 = row8_sum(m2);
         if ((threadIdx.x & 7) == 0) {
             f32x2 w;
-            w[0] = s1; w[1] = s2;
+            w[0] = s1; w[1] = m2;
             *(f32x2*)sptr = w;
         }
     }

@@ -100,8 +100,9 @@ struct EpiParams {
     //   v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]      with bias[n] = sum_k beta[k] W[n,k] + b[n]
     const float* ln_stats;   // [M][2] = (mean, rstd) per row, or null
     const float* ln_colsum;  // [N]    = sum_k (gamma[k] W[n,k])
-    // Row statistics of the OUTPUT for the next LayerNorm: (sum, sum of squares) of the rounded outputs per
-    // (row, 64-column block), written - not accumulated - so the result is deterministic and needs no zeroing.
+    // Row statistics of the OUTPUT for the next LayerNorm: (sum, sum of squared deviations from the block mean) of the
+    // rounded outputs per (row, 64-column block), written - not accumulated - so the result is deterministic and needs no
+    // zeroing; leclip_ln_stats_finalize_fwd merges the blocks (parallel-variance update, no E[x^2] - mean^2 cancellation).
     float* stats_out;        // [M][stats_slots][2] or null
     int stats_slots;
 };
@@ -151,7 +152,7 @@ __device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n,
             for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
         }
     }
-    float s1 = 0.f, s2 = 0.f;
+    float rv[8];   // the values as stored (rounded to the output type): what the next LayerNorm will see
     if (e.out_dt == LECLIP_F32) {
         float* op = (float*)e.out + orow * e.ldy + n;
         f32x4 o0, o1;
@@ -160,29 +161,39 @@ __device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n,
         *(f32x4*)op = o0;
         *(f32x4*)(op + 4) = o1;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { s1 += v[c]; s2 = fmaf(v[c], v[c], s2); }
+        for (int c = 0; c < 8; ++c) rv[c] = v[c];
     } else if (e.out_dt == LECLIP_BF16) {
         bf16x8 o8;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o8[c] = (bf16_t)v[c];
         *(bf16x8*)((bf16_t*)e.out + orow * e.ldy + n) = o8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { const float r = (float)o8[c]; s1 += r; s2 = fmaf(r, r, s2); }
+        for (int c = 0; c < 8; ++c) rv[c] = (float)o8[c];
     } else {
         f16x8 o8;
 #pragma unroll
         for (int c = 0; c < 8; ++c) o8[c] = (f16_t)v[c];
         *(f16x8*)((f16_t*)e.out + orow * e.ldy + n) = o8;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { const float r = (float)o8[c]; s1 += r; s2 = fmaf(r, r, s2); }
+        for (int c = 0; c < 8; ++c) rv[c] = (float)o8[c];
     }
     if (e.stats_out) {
-        // the 8 lanes of a row (consecutive lanes) hold its 64 columns of this wave: butterfly, lane 0 of the group writes
+        // (sum, M2 about the block mean) of the 64-column block; the 8 lanes of a row (consecutive lanes) hold its 64 columns
+        // of this wave: butterfly (same additions, in the same order, as the DPP form of gemm_mfma256.hip), lane 0 writes
+        float s1 = 0.f;
 #pragma unroll
-        for (int o = 1; o < 8; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        for (int c = 0; c < 8; ++c) s1 += rv[c];
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) s1 += __shfl_xor(s1, o);
+        const float mb = s1 * (1.0f / 64.0f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { const float dlt = rv[c] - mb; m2 = fmaf(dlt, dlt, m2); }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) m2 += __shfl_xor(m2, o);
         if ((threadIdx.x & 7) == 0) {
             f32x2 w;
-            w[0] = s1; w[1] = s2;
+            w[0] = s1; w[1] = m2;
             *(f32x2*)(e.stats_out + (orow * e.stats_slots + (n >> 6)) * 2) = w;
         }
     }

@@ -125,18 +125,22 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const TI* __restrict__ x
     if (lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = rsqrtf(q / (float)dim + eps); }
 }
 
-// Reduce the per-(row, 64-column block) partial sums a GEMM epilogue wrote into (mean, rstd): fixed summation order.
+// Merge the per-(row, 64-column block) partials (sum, M2 about the block mean) a GEMM epilogue wrote into (mean, rstd):
+// mean = sum of sums / dim, M2 = sum_b [ M2_b + 64 (mean_b - mean)^2 ]  (Chan et al.'s parallel-variance update, fixed block
+// order): every term is a sum of squares of deviations, so rows whose mean dwarfs their spread lose nothing to cancellation.
 __global__ void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows, int slots,
                                          int dim, float eps) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     const f32x2* p = (const f32x2*)(partials + r * slots * 2);
-    float s1 = 0.f, s2 = 0.f;
-    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; s1 += t[0]; s2 += t[1]; }
+    float s1 = 0.f;
+    for (int i = 0; i < slots; ++i) s1 += p[i][0];
     const float mean = s1 / (float)dim;
-    const float var = fmaxf(s2 / (float)dim - mean * mean, 0.f);
+    const float bn = (float)(dim / slots);
+    float m2 = 0.f;
+    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
     stats[2 * r] = mean;
-    stats[2 * r + 1] = rsqrtf(var + eps);
+    stats[2 * r + 1] = rsqrtf(m2 / (float)dim + eps);
 }
 
 // ------------------------------------------------------------------------- gather + LayerNorm + projection

@@ -1,0 +1,322 @@
+// The tail of the scoring path as ONE kernel: class-token gather -> ln_post -> @ proj -> L2-normalise -> scale * img . txt^T
+// (clip/model.py:271-274, 399-404; trainers/Caption_distill_double.py:330-335), both contractions on the matrix cores:
+//   * the projection [16 images, d] x [E, d]^T with v_mfma_f32_16x16x32 (bf16 / fp16 operands, the same instruction and
+//     ascending-K order as the GEMM kernels) or, in the fp32 parity mode, the exact v_mfma_f32_16x16x4_f32;
+//   * the cosine-logit contraction [16, E] x [C, E]^T on the fp32 features with v_mfma_f32_16x16x4_f32 (exact fp32: the
+//     features are never rounded to 16 bits), divided by the two norms afterwards like the reference's normalise-then-dot.
+// One 256-thread workgroup per 16 images; LayerNorm output and features live in LDS; proj^T and the text features are read
+// straight from L2 (0.8 MB + 0.16 MB, shared by every workgroup).  Replaces three launches (LayerNorm, projection GEMM,
+// one-thread-per-logit kernel) of round 1.  Also here: the small row-wise helpers of the prompt-tuning backward
+// (cosine-logit backward w.r.t. the text features, row gather / scatter).
+#include "leclip_common.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) float acc4;
+__device__ __forceinline__ acc4 mfma16(bf16x8 a, bf16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ acc4 mfma16(f16x8 a, f16x8 b, acc4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <typename T> __device__ __forceinline__ f32x4 tload4(const T* p);
+template <> __device__ __forceinline__ f32x4 tload4<float>(const float* p) { return *(const f32x4*)p; }
+template <> __device__ __forceinline__ f32x4 tload4<bf16_t>(const bf16_t* p) {
+    const bf16x4 v = *(const bf16x4*)p; f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)v[i]; return r;
+}
+template <> __device__ __forceinline__ f32x4 tload4<f16_t>(const f16_t* p) {
+    const f16x4 v = *(const f16x4*)p; f32x4 r; for (int i = 0; i < 4; ++i) r[i] = (float)v[i]; return r;
+}
+template <typename T> __device__ __forceinline__ void tstore4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void tstore4<float>(float* p, f32x4 v) { *(f32x4*)p = v; }
+template <> __device__ __forceinline__ void tstore4<bf16_t>(bf16_t* p, f32x4 v) { bf16x4 r; for (int i = 0; i < 4; ++i) r[i] = (bf16_t)v[i]; *(bf16x4*)p = r; }
+template <> __device__ __forceinline__ void tstore4<f16_t>(f16_t* p, f32x4 v) { f16x4 r; for (int i = 0; i < 4; ++i) r[i] = (f16_t)v[i]; *(f16x4*)p = r; }
+
+struct TailArgs {
+    const void* x;          // residual stream; image b's class-token row starts at x + b * row_stride (elements)
+    const float* gamma;
+    const float* beta;
+    const void* proj_t;     // [E, d], K contiguous, same dtype as x
+    const float* txt;       // [C, E] fp32 text features (un-normalised) or null (features only)
+    float* feat;            // [B, E] fp32 or null
+    float* logits;          // [B, C] fp32 or null
+    int64_t B, row_stride;
+    int d, E, C;
+    float eps, scale;
+};
+
+constexpr int TAIL_MAXV = 4;   // d <= 1024
+
+// proj GEMM for one wave: columns [n_lo, n_hi) in tiles of 16, A = LayerNorm output in LDS
+template <typename T>
+__device__ __forceinline__ void proj_tiles(const TailArgs& a, const char* sh, int hpitch, float* sfeat, int fpitch, int wave, int lane) {
+    typedef typename VecOf<T>::v8 v8;
+    const int fr = lane & 15, fc = lane >> 4;
+    const T* P = (const T*)a.proj_t;
+    for (int nt = wave; nt * 16 < a.E; nt += 4) {
+        acc4 acc = {0.f, 0.f, 0.f, 0.f};
+        const T* prow = P + (int64_t)(nt * 16 + fr) * a.d + fc * 8;
+        const char* hrow = sh + fr * hpitch + fc * 16;
+        for (int k = 0; k < a.d; k += 32) {
+            const v8 af = *(const v8*)(hrow + k * 2);
+            const v8 bf = *(const v8*)(prow + k);
+            acc = mfma16(af, bf, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sfeat[(4 * fc + r) * fpitch + nt * 16 + fr] = acc[r];
+    }
+}
+template <>
+__device__ __forceinline__ void proj_tiles<float>(const TailArgs& a, const char* sh, int hpitch, float* sfeat, int fpitch, int wave, int lane) {
+    // exact fp32: v_mfma_f32_16x16x4_f32, K taken in groups of 16 with MFMA j / slot q <-> k = 16g + 4q + j, so that a lane's
+    // four operands of a group are 16 contiguous bytes on both sides
+    const int fr = lane & 15, fq = lane >> 4;
+    const float* P = (const float*)a.proj_t;
+    for (int nt = wave; nt * 16 < a.E; nt += 4) {
+        acc4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* prow = P + (int64_t)(nt * 16 + fr) * a.d + 4 * fq;
+        const char* hrow = sh + fr * hpitch + 16 * fq;
+        for (int k = 0; k < a.d; k += 16) {
+            const f32x4 af = *(const f32x4*)(hrow + k * 4);
+            const f32x4 bf = *(const f32x4*)(prow + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sfeat[(4 * fq + r) * fpitch + nt * 16 + fr] = acc[r];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hpitch = a.d * (int)sizeof(T) + 16;          // +16 B: the 16 rows of a fragment read fall on distinct banks
+    const int fpitch = a.E + 4;
+    char* sh = smem;                                       // [16][hpitch]   LayerNorm output, operand dtype
+    float* sfeat = (float*)(smem + 16 * hpitch);           // [16][E + 4]    projected features, fp32
+    float* sinorm = sfeat + 16 * fpitch;                   // [16]           |feature|^2
+    float* stnorm = sinorm + 16;                           // [C]            |text feature|^2
+    const int64_t b0 = (int64_t)blockIdx.x * 16;
+
+    // ---- ln_post on the class-token rows: one wave per row, 4 rows per wave; two-pass fp32 statistics (as layernorm_kernel)
+    const int nv = a.d >> 8, tail = a.d & 255;
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr;
+        int64_t b = b0 + row;
+        b = b < a.B ? b : a.B - 1;
+        const T* xr = (const T*)a.x + b * a.row_stride;
+        f32x4 v[TAIL_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < TAIL_MAXV; ++i)
+            if (i < nv || (i == nv && lane * 4 < tail)) { v[i] = tload4<T>(xr + i * 256 + lane * 4); s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]); }
+        const float mean = wave_sum(s) / (float)a.d;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < TAIL_MAXV; ++i)
+            if (i < nv || (i == nv && lane * 4 < tail)) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dlt = v[i][e] - mean; q = fmaf(dlt, dlt, q); }
+            }
+        const float rstd = rsqrtf(wave_sum(q) / (float)a.d + a.eps);
+#pragma unroll
+        for (int i = 0; i < TAIL_MAXV; ++i)
+            if (i < nv || (i == nv && lane * 4 < tail)) {
+                const int c = i * 256 + lane * 4;
+                const f32x4 g = *(const f32x4*)(a.gamma + c), bt = *(const f32x4*)(a.beta + c);
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+                tstore4<T>((T*)(sh + row * hpitch) + c, o);
+            }
+    }
+    // |t_c|^2 of the text features (every workgroup needs all C of them: 0.16 MB from L2)
+    if (a.txt) {
+        for (int c = wave; c < a.C; c += 4) {
+            const float* tr = a.txt + (int64_t)c * a.E;
+            float s = 0.f;
+            for (int k = lane * 4; k < a.E; k += 256) { const f32x4 t = *(const f32x4*)(tr + k); s = fmaf(t[0], t[0], s); s = fmaf(t[1], t[1], s); s = fmaf(t[2], t[2], s); s = fmaf(t[3], t[3], s); }
+            s = wave_sum(s);
+            if (lane == 0) stnorm[c] = s;
+        }
+    }
+    __syncthreads();
+
+    // ---- features = LN(x_cls) @ proj on the matrix cores
+    proj_tiles<T>(a, sh, hpitch, sfeat, fpitch, wave, lane);
+    __syncthreads();
+    for (int rr = 0; rr < 4; ++rr) {
+        const int row = wave * 4 + rr;
+        const float* fr_ = sfeat + row * fpitch;
+        float s = 0.f;
+        for (int k = lane * 4; k < a.E; k += 256) {
+            const f32x4 t = *(const f32x4*)(fr_ + k);
+            s = fmaf(t[0], t[0], s); s = fmaf(t[1], t[1], s); s = fmaf(t[2], t[2], s); s = fmaf(t[3], t[3], s);
+            if (a.feat && b0 + row < a.B) *(f32x4*)(a.feat + (b0 + row) * a.E + k) = t;
+        }
+        s = wave_sum(s);
+        if (lane == 0) sinorm[row] = s;
+    }
+    if (!a.txt || !a.logits) return;
+    __syncthreads();
+
+    // ---- logits[b, c] = scale * <f_b, t_c> / (|f_b| |t_c|): exact-fp32 MFMA, K in groups of 16 (slot q <-> k = 16g + 4q + j)
+    const int fr = lane & 15, fq = lane >> 4;
+    for (int ct = wave; ct * 16 < a.C; ct += 4) {
+        int c = ct * 16 + fr;
+        const int cc = c < a.C ? c : a.C - 1;
+        const float* trow = a.txt + (int64_t)cc * a.E + 4 * fq;
+        const float* frow = sfeat + fr * fpitch + 4 * fq;
+        acc4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < a.E; k += 16) {
+            const f32x4 af = *(const f32x4*)(frow + k);
+            const f32x4 bf = *(const f32x4*)(trow + k);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[j], bf[j], acc, 0, 0, 0);
+        }
+        if (c < a.C) {
+            const float tn = sqrtf(stnorm[c]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 4 * fq + r;
+                if (b0 + row < a.B) a.logits[(b0 + row) * a.C + c] = (a.scale * acc[r]) / (sqrtf(sinorm[row]) * tn);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// d txt of logits = scale * normalize(img) . normalize(txt)^T (image features frozen):
+//   g_c = scale * sum_b dlogits[b, c] * img_b / |img_b|,   dtxt_c = (g_c - that_c <g_c, that_c>) / |txt_c|
+// One workgroup per class; the image rows' inverse norms are formed once per workgroup in LDS (chunks of 2048 images).
+constexpr int LB_CHUNK = 2048;
+__global__ __launch_bounds__(256) void logits_bwd_kernel(const float* __restrict__ img, const float* __restrict__ txt,
+                                                         const float* __restrict__ dlogits, float* __restrict__ dtxt, int64_t B, int C,
+                                                         int D, float scale) {
+    __shared__ float invn[LB_CHUNK];
+    __shared__ float red[8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x;
+    float g[4] = {0.f, 0.f, 0.f, 0.f};      // D <= 1024: thread owns d = tid, tid + 256, ...
+    for (int64_t bb = 0; bb < B; bb += LB_CHUNK) {
+        const int nb = (int)(B - bb < LB_CHUNK ? B - bb : LB_CHUNK);
+        __syncthreads();
+        for (int i = wave; i < nb; i += 4) {
+            const float* r = img + (bb + i) * D;
+            float s = 0.f;
+            for (int k = lane; k < D; k += 64) s = fmaf(r[k], r[k], s);
+            s = wave_sum(s);
+            if (lane == 0) invn[i] = 1.0f / sqrtf(s);
+        }
+        __syncthreads();
+        for (int i = 0; i < nb; ++i) {
+            const float w = dlogits[(bb + i) * C + c] * invn[i];
+            const float* r = img + (bb + i) * D;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int k = tid + 256 * u; if (k < D) g[u] = fmaf(w, r[k], g[u]); }
+        }
+    }
+    const float* t = txt + (int64_t)c * D;
+    float tt = 0.f, gt = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int k = tid + 256 * u; if (k < D) { g[u] *= scale; tt = fmaf(t[k], t[k], tt); gt = fmaf(g[u], t[k], gt); } }
+    tt = wave_sum(tt);
+    gt = wave_sum(gt);
+    __syncthreads();
+    if (lane == 0) { red[wave] = tt; red[4 + wave] = gt; }
+    __syncthreads();
+    tt = (red[0] + red[1]) + (red[2] + red[3]);
+    gt = (red[4] + red[5]) + (red[6] + red[7]);
+    const float tn = sqrtf(tt);
+    // that = t / tn;  <g, that> = gt / tn;  dtxt = (g - that * gt / tn) / tn
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int k = tid + 256 * u; if (k < D) dtxt[(int64_t)c * D + k] = (g[u] - t[k] * (gt / tt)) / tn; }
+}
+
+// dst[i, :] = src[index[i], :]   /   dst[index[i], :] = src[i, :]   (rows of `dim` elements of `esize` bytes, 16-byte chunks)
+__global__ void move_rows_kernel(const char* __restrict__ src, const int64_t* __restrict__ index, char* __restrict__ dst, int64_t n,
+                                 int row_bytes, int64_t src_pitch, int64_t dst_pitch, int scatter) {
+    const int64_t i = blockIdx.x;
+    if (i >= n) return;
+    const int64_t j = index[i];
+    const char* s = src + (scatter ? i : j) * src_pitch;
+    char* d = dst + (scatter ? j : i) * dst_pitch;
+    for (int k = threadIdx.x * 16; k < row_bytes; k += blockDim.x * 16) *(i32x4*)(d + k) = *(const i32x4*)(s + k);
+}
+
+template <typename T>
+int launch_tail(const TailArgs& a, hipStream_t s) {
+    const int lds = 16 * (a.d * (int)sizeof(T) + 16) + (16 * (a.E + 4) + 16 + a.C) * 4;
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(image_tail_kernel<T>, 160 * 1024, attr_set);
+    hipLaunchKernelGGL((image_tail_kernel<T>), dim3((unsigned)((a.B + 15) / 16)), dim3(256), lds, s, a);
+    return leclip_check_launch("image_tail_kernel");
+}
+
+}  // namespace
+
+extern "C" int leclip_image_tail_fwd(const void* x, const float* gamma, const float* beta, const void* proj_t, const float* txt,
+                                     float* feat, float* logits, int64_t B, int64_t row_stride, int dim, int E, int C, float eps,
+                                     float scale, leclip_dtype dtype, void* stream) {
+    if (!x || !gamma || !beta || !proj_t || B <= 0 || dim <= 0 || E <= 0 || row_stride < dim || (!feat && !logits) || (logits && (!txt || C <= 0))) {
+        leclip_set_error("image_tail: null pointer or inconsistent sizes");
+        return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(dtype)) { leclip_set_error("image_tail: bad dtype"); return LECLIP_E_INVALID; }
+    const int kq = dtype == LECLIP_F32 ? 16 : 32;
+    if (dim % 64 != 0 || dim > 256 * TAIL_MAXV || dim % kq != 0 || E % 16 != 0 || E > 2048 || C > 4096) {
+        leclip_set_error("image_tail: dim=%d must be a multiple of 64 and <= %d, E=%d a multiple of 16 (<= 2048), C=%d <= 4096", dim, 256 * TAIL_MAXV, E, C);
+        return LECLIP_E_UNSUPPORTED;
+    }
+    const int esz = dtype_size(dtype);
+    if (((uintptr_t)x & 15) || ((row_stride * esz) & 15) || ((uintptr_t)proj_t & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15) ||
+        (txt && ((uintptr_t)txt & 15)) || (feat && ((uintptr_t)feat & 15))) {
+        leclip_set_error("image_tail: x / proj_t / gamma / beta / txt / feat must be 16-byte aligned (row stride a multiple of 16 bytes)");
+        return LECLIP_E_INVALID;
+    }
+    TailArgs a;
+    a.x = x; a.gamma = gamma; a.beta = beta; a.proj_t = proj_t; a.txt = logits ? txt : nullptr; a.feat = feat; a.logits = logits;
+    a.B = B; a.row_stride = row_stride; a.d = dim; a.E = E; a.C = logits ? C : 0; a.eps = eps; a.scale = scale;
+    const size_t lds = 16 * ((size_t)dim * esz + 16) + (16 * ((size_t)E + 4) + 16 + a.C) * 4;
+    if (lds > 160 * 1024) { leclip_set_error("image_tail: dim=%d E=%d C=%d needs %zu bytes of LDS", dim, E, C, lds); return LECLIP_E_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == LECLIP_F32) return launch_tail<float>(a, s);
+    if (dtype == LECLIP_F16) return launch_tail<f16_t>(a, s);
+    return launch_tail<bf16_t>(a, s);
+}
+
+extern "C" int leclip_l2norm_logits_bwd(const float* img, const float* txt, const float* dlogits, float* dtxt, int64_t B, int C, int D,
+                                        float scale, void* stream) {
+    if (!img || !txt || !dlogits || !dtxt || B <= 0 || C <= 0 || D <= 0) { leclip_set_error("logits_bwd: null pointer or bad size"); return LECLIP_E_INVALID; }
+    if (D > 1024) { leclip_set_error("logits_bwd: D=%d > 1024", D); return LECLIP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(logits_bwd_kernel, dim3((unsigned)C), dim3(256), 0, (hipStream_t)stream, img, txt, dlogits, dtxt, B, C, D, scale);
+    return leclip_check_launch("logits_bwd_kernel");
+}
+
+static int move_rows(const void* src, const int64_t* index, void* dst, int64_t n, int dim, int64_t ld_src, int64_t ld_dst, int dtype,
+                     int scatter, int64_t dst_rows, void* stream, const char* what) {
+    if (!src || !index || !dst || n <= 0 || dim <= 0 || ld_src < dim || ld_dst < dim || !dtype_ok((leclip_dtype)dtype)) {
+        leclip_set_error("%s: null pointer or bad size", what);
+        return LECLIP_E_INVALID;
+    }
+    const int esz = dtype_size(dtype);
+    if (((int64_t)dim * esz) % 16 || (ld_src * esz) % 16 || (ld_dst * esz) % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        leclip_set_error("%s: rows must be multiples of 16 bytes, 16-byte aligned", what);
+        return LECLIP_E_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (scatter && hipMemsetAsync(dst, 0, (size_t)dst_rows * ld_dst * esz, s) != hipSuccess) { leclip_set_error("%s: memset failed", what); return LECLIP_E_LAUNCH; }
+    hipLaunchKernelGGL(move_rows_kernel, dim3((unsigned)n), dim3(64), 0, s, (const char*)src, index, (char*)dst, n, dim * esz, ld_src * esz,
+                       ld_dst * esz, scatter);
+    return leclip_check_launch(what);
+}
+
+extern "C" int leclip_gather_rows_fwd(const void* src, const int64_t* index, void* dst, int64_t n, int dim, int64_t ld_src, int64_t ld_dst,
+                                      leclip_dtype dtype, void* stream) {
+    return move_rows(src, index, dst, n, dim, ld_src, ld_dst, (int)dtype, 0, 0, stream, "gather_rows");
+}
+
+extern "C" int leclip_scatter_rows_fwd(const void* src, const int64_t* index, void* dst, int64_t n, int64_t dst_rows, int dim, int64_t ld_src,
+                                       int64_t ld_dst, leclip_dtype dtype, void* stream) {
+    if (dst_rows <= 0) { leclip_set_error("scatter_rows: bad size"); return LECLIP_E_INVALID; }
+    return move_rows(src, index, dst, n, dim, ld_src, ld_dst, (int)dtype, 1, dst_rows, stream, "scatter_rows");
+}

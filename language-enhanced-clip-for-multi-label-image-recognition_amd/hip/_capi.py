@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 PACKAGE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libleclip_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU = 0, 1
@@ -61,6 +61,13 @@ SIGNATURES = {
     "leclip_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int, c_float,
                                      c_int, c_void_p]),
     "leclip_eot_index_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "leclip_image_tail_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int,
+                                      c_int, c_int, c_float, c_float, c_int, c_void_p]),
+    "leclip_l2norm_logits_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "leclip_gather_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "leclip_scatter_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "leclip_crop_resize_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.POINTER(c_float),
+                                       ctypes.POINTER(c_float), c_int, c_void_p]),
 }
 
 _lib = None

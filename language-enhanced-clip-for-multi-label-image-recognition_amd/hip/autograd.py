@@ -62,10 +62,9 @@ class TextTowerFunction(torch.autograd.Function):
         bw = _bwd_weights(engine)
         # features = LN(x[eot]) @ proj: d(LN out) = dfeat @ proj^T  (proj [d, E] is already the [N'=d, K'=E] layout)
         dln = ops.gemm(dfeat.to(dt).contiguous(), engine.proj)
-        rows = ctx.x_last[ctx.flat].contiguous()
+        rows = ops.gather_rows(ctx.x_last, ctx.flat)
         drows = ops.layernorm_bwd(dln, rows, engine.ln_w)
-        dx = torch.zeros((n * t, d), dtype=dt, device=dfeat.device)
-        dx.index_copy_(0, ctx.flat, drows)
+        dx = ops.scatter_rows(drows, ctx.flat, n * t)        # zero everywhere but the EOT rows
         for p, w, (x_in, qkv, x_mid, pre) in zip(reversed(engine.blocks), reversed(bw), reversed(ctx.saved)):
             du = ops.gemm(dx, w.pr_t)                                   # through c_proj
             dpre = ops.quickgelu_bwd(pre, du)
@@ -96,8 +95,7 @@ class PromptAssembleFunction(torch.autograd.Function):
 
 class CosineLogitsFunction(torch.autograd.Function):
     """logits = scale * normalize(img) @ normalize(txt).T (CDD.py:330-335) with the gradient w.r.t. the text features
-    (image features come from frozen encoders: no gradient).  The [C,B]x[B,E] contraction of the backward runs on the
-    exact-fp32 MFMA GEMM; the normalisation Jacobian is a few elementwise ops on a [C, E] matrix."""
+    (image features come from frozen encoders: no gradient): one kernel, leclip_l2norm_logits_bwd."""
 
     @staticmethod
     def forward(ctx, img: torch.Tensor, txt: torch.Tensor, scale: float):
@@ -110,19 +108,4 @@ class CosineLogitsFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits: torch.Tensor):
         img, txt = ctx.saved_tensors
-        b, e = img.shape
-        inorm = img / img.norm(dim=-1, keepdim=True)
-        tn = txt.norm(dim=-1, keepdim=True)
-        that = txt / tn
-        pad = (-b) % 32                       # the fp32 GEMM wants K % 32 == 0
-        dl_t = dlogits.float().t().contiguous()            # [C, B]
-        in_t = inorm.t().contiguous()                      # [E, B]  = W' with N' = E, K' = B
-        if pad:
-            dl_t = torch.nn.functional.pad(dl_t, (0, pad))
-            in_t = torch.nn.functional.pad(in_t, (0, pad))
-        if e % 64 == 0:
-            dthat = ops.gemm(dl_t.contiguous(), in_t.contiguous()) * ctx.scale      # [C, E]
-        else:                                   # odd embed dims (tiny test models): tiny host-side product
-            dthat = (dl_t @ in_t.t()) * ctx.scale
-        dtxt = (dthat - that * (dthat * that).sum(dim=-1, keepdim=True)) / tn
-        return None, dtxt, None
+        return None, ops.l2norm_logits_bwd(img, txt, dlogits.float().contiguous(), ctx.scale), None

@@ -158,9 +158,7 @@ class VisionEngine:
         self.ln_pre_w, self.ln_pre_b = _f32(visual.ln_pre.weight, device), _f32(visual.ln_pre.bias, device)
         self.ln_post_w, self.ln_post_b = _f32(visual.ln_post.weight, device), _f32(visual.ln_post.bias, device)
         self.proj = visual.proj.detach().to(device=device, dtype=dtype).contiguous()
-        e = self.proj.shape[1]
-        ok = (e % 128 == 0 and self.width % 64 == 0) if dtype != torch.float32 else (e % 64 == 0 and self.width % 32 == 0)
-        self.proj_t = self.proj.t().contiguous() if ok else None   # [E, d] nn.Linear layout for the projection GEMM
+        self.proj_t = self.proj.t().contiguous()   # [E, d]: K-contiguous B operand of the tail kernel's projection
         self.blocks = pack_blocks(visual.transformer.resblocks, dtype, device)
         self._ws: Dict[int, tuple] = {}
 
@@ -180,7 +178,7 @@ class VisionEngine:
             )
         return self._ws[key]
 
-    def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+    def _trunk(self, image: torch.Tensor, taps: Optional[dict] = None):
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.resolution or image.shape[3] != self.resolution:
             raise ValueError(f"image must be [B,3,{self.resolution},{self.resolution}], got {tuple(image.shape)}")
         batch = image.shape[0]
@@ -194,13 +192,28 @@ class VisionEngine:
         if taps is not None:
             taps["ln_pre"] = x.float().clone()
         run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps)
-        # ln_post on the class token only, then @ proj (clip/model.py:271-274); fp32 features.  The class rows sit at a
-        # fixed stride (T*d), so LayerNorm reads them in place (ldx = T*d) and the projection is a small MFMA GEMM.
-        if self.proj_t is not None:
-            cls = x.view(batch, self.tokens * self.width)[:, :self.width]
-            h = ops.layernorm(cls, self.ln_post_w, self.ln_post_b)
-            return ops.gemm(h, self.proj_t, out_dtype=torch.float32)
-        return ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)
+        return x, batch, cls_rows
+
+    def _tail(self, x: torch.Tensor, batch: int, cls_rows, text_features: Optional[torch.Tensor], scale: float, want_features: bool):
+        # ln_post on the class token only, then @ proj (clip/model.py:271-274) and - when text features are given - the
+        # normalised, scaled cosine logits (model.py:399-404): ONE launch, both contractions on the matrix cores
+        # (leclip_image_tail_fwd).  The class rows sit at a fixed stride (T*d) and are read in place.
+        e = self.proj.shape[1]
+        if self.width % 64 == 0 and self.width <= 1024 and e % 16 == 0:
+            return ops.image_tail(x, batch, self.tokens * self.width, self.ln_post_w, self.ln_post_b, self.proj_t, text_features, scale,
+                                  want_features)
+        feat = ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)     # odd widths (tiny test towers)
+        return feat, (ops.l2norm_logits(feat, text_features, scale) if text_features is not None else None)
+
+    def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
+        """Image features [B, E] fp32 (VisionTransformer.forward)."""
+        x, batch, cls_rows = self._trunk(image, taps)
+        return self._tail(x, batch, cls_rows, None, 1.0, True)[0]
+
+    def score(self, image: torch.Tensor, text_features: torch.Tensor, scale: float, want_features: bool = False):
+        """(features or None, logits [B, C]): the image tower with the cosine-logit contraction folded into its tail kernel."""
+        x, batch, cls_rows = self._trunk(image)
+        return self._tail(x, batch, cls_rows, text_features.float().contiguous(), scale, want_features)
 
 
 class TextEngine:

@@ -375,3 +375,80 @@ def cooccurrence_adjust(p: torch.Tensor, mn: torch.Tensor, weight: float = 0.5) 
     out = torch.empty_like(p)
     _capi.check(_capi.load().leclip_cooccurrence_adjust_fwd(_ptr(p), _ptr(mn), _ptr(out), b, c, weight, _stream()), "cooccurrence_adjust")
     return out
+
+
+# ------------------------------------------------------------------------------------------- fused image tail / helpers
+def image_tail(x: torch.Tensor, batch: int, row_stride: int, gamma: torch.Tensor, beta: torch.Tensor, proj_t: torch.Tensor,
+               txt: Optional[torch.Tensor] = None, scale: float = 4.0, want_features: bool = False, eps: float = 1e-5):
+    """ln_post(class rows) @ proj -> (features [B,E] fp32 or None, logits [B,C] fp32 or None) in one launch
+    (leclip_image_tail_fwd).  ``x`` holds image b's class-token row at element offset ``b * row_stride``."""
+    _dev(x, "x"), _dev(proj_t, "proj_t")
+    e, dim = proj_t.shape
+    assert proj_t.is_contiguous() and proj_t.dtype == x.dtype and x.is_contiguous()
+    feat = torch.empty((batch, e), dtype=torch.float32, device=x.device) if (want_features or txt is None) else None
+    logits, c = None, 0
+    if txt is not None:
+        _dev(txt, "text_features")
+        assert txt.dtype == torch.float32 and txt.is_contiguous() and txt.shape[1] == e
+        c = txt.shape[0]
+        logits = torch.empty((batch, c), dtype=torch.float32, device=x.device)
+    with _Timed("image_tail", 2 * batch * e * (dim + c), batch * dim * x.element_size() + e * dim * x.element_size() + c * e * 4):
+        _capi.check(_capi.load().leclip_image_tail_fwd(_ptr(x), _ptr(_dev(gamma, "gamma")), _ptr(_dev(beta, "beta")), _ptr(proj_t), _ptr(txt),
+                                                       _ptr(feat), _ptr(logits), batch, row_stride, dim, e, c, eps, float(scale),
+                                                       dtype_code(x.dtype), _stream()), "image_tail")
+    return feat, logits
+
+
+def l2norm_logits_bwd(img: torch.Tensor, txt: torch.Tensor, dlogits: torch.Tensor, scale: float) -> torch.Tensor:
+    """d(text features) of ``l2norm_logits`` (image features frozen)."""
+    for name, t in (("image_features", img), ("text_features", txt), ("dlogits", dlogits)):
+        _dev(t, name)
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise TypeError(f"l2norm_logits_bwd: {name} must be contiguous float32")
+    b, d = img.shape
+    c = txt.shape[0]
+    assert txt.shape == (c, d) and dlogits.shape == (b, c)
+    out = torch.empty_like(txt)
+    _capi.check(_capi.load().leclip_l2norm_logits_bwd(_ptr(img), _ptr(txt), _ptr(dlogits), _ptr(out), b, c, d, float(scale), _stream()),
+                "l2norm_logits_bwd")
+    return out
+
+
+def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+    """src[index] for a 2-D row-major tensor (device-side row copy, no ATen indexing kernel)."""
+    rows, dim, ld = _rows2d(src, "src")
+    assert index.dtype == torch.int64 and index.is_contiguous()
+    out = torch.empty((index.numel(), dim), dtype=src.dtype, device=src.device)
+    _capi.check(_capi.load().leclip_gather_rows_fwd(_ptr(src), _ptr(_dev(index, "index")), _ptr(out), index.numel(), dim, ld, dim,
+                                                    dtype_code(src.dtype), _stream()), "gather_rows")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, index: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """zeros([n_rows, dim]) with row index[i] = src[i] (indices distinct)."""
+    n, dim, ld = _rows2d(src, "src")
+    assert index.dtype == torch.int64 and index.is_contiguous() and index.numel() == n
+    out = torch.empty((n_rows, dim), dtype=src.dtype, device=src.device)
+    _capi.check(_capi.load().leclip_scatter_rows_fwd(_ptr(src), _ptr(_dev(index, "index")), _ptr(out), n, n_rows, dim, ld, dim,
+                                                     dtype_code(src.dtype), _stream()), "scatter_rows")
+    return out
+
+
+def crop_resize(src_u8: torch.Tensor, windows: torch.Tensor, size: int, mean, std, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """[B,3,H,W] uint8 images x [NW,5] int32 windows (y0, x0, rows, cols, pad_top) -> [B, NW, 3, size, size]: the reference's
+    per-window test transform (bicubic Resize on the smaller edge, CenterCrop, ToTensor, Normalize) on the device,
+    bit-compatible with Pillow's resampler (leclip_crop_resize_fwd)."""
+    import ctypes
+    _dev(src_u8, "src"), _dev(windows, "windows")
+    if src_u8.dim() == 3:
+        src_u8 = src_u8.unsqueeze(0)
+    assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and src_u8.shape[1] == 3
+    assert windows.dtype == torch.int32 and windows.is_contiguous() and windows.dim() == 2 and windows.shape[1] == 5
+    b, _, h, w = src_u8.shape
+    nw = windows.shape[0]
+    out = torch.empty((b, nw, 3, size, size), dtype=out_dtype, device=src_u8.device)
+    m3 = (ctypes.c_float * 3)(*[float(v) for v in mean])
+    s3 = (ctypes.c_float * 3)(*[float(v) for v in std])
+    _capi.check(_capi.load().leclip_crop_resize_fwd(_ptr(src_u8), b, h, w, _ptr(windows), nw, _ptr(out), size, m3, s3, dtype_code(out_dtype),
+                                                    _stream()), "crop_resize")
+    return out

@@ -257,6 +257,23 @@ def make_images(batch: int, resolution: int = 224, seed: int = 1234, start: int 
     return out
 
 
+def make_u8_image(height: int, width: int, seed: int = 5, index: int = 0) -> np.ndarray:
+    """uint8 [3, H, W] "photograph" for the multi-crop test path (the raw image a DatasetWrapperWithBlock item is cropped
+    from, dassl/data/data_manager.py:348-492): a random 16-pixel grid blended bilinearly plus +-24 noise.  Integer
+    arithmetic only, so the bytes are identical on every host."""
+    gh, gw = height // 16 + 2, width // 16 + 2
+    n_grid = 3 * gh * gw
+    grid = (uniform_u16x8_sum(seed, f"u8image.{index}.grid", n_grid) % 256).reshape(3, gh, gw)
+    noise = (uniform_u16x8_sum(seed, f"u8image.{index}.noise", 3 * height * width) % 49 - 24).reshape(3, height, width)
+    y, x = np.arange(height, dtype=np.int64), np.arange(width, dtype=np.int64)
+    iy, fy, ix, fx = y // 16, y % 16, x // 16, x % 16
+    g00, g01 = grid[:, iy][:, :, ix], grid[:, iy][:, :, ix + 1]
+    g10, g11 = grid[:, iy + 1][:, :, ix], grid[:, iy + 1][:, :, ix + 1]
+    wy0, wy1, wx0, wx1 = (16 - fy)[None, :, None], fy[None, :, None], (16 - fx)[None, None, :], fx[None, None, :]
+    v = (wy0 * (wx0 * g00 + wx1 * g01) + wy1 * (wx0 * g10 + wx1 * g11)) // 256 + noise
+    return np.clip(v, 0, 255).astype(np.uint8)
+
+
 def make_ctx(n_ctx: int, dim: int, seed: int = 0, name: str = "ctx", n_cls: Optional[int] = None) -> np.ndarray:
     """Learnable-context init N(0, 0.02^2) (Caption_distill_double.py:128-134)."""
     shape = (n_ctx, dim) if n_cls is None else (n_cls, n_ctx, dim)

@@ -219,12 +219,16 @@ class CustomCLIP(nn.Module):
     def forward(self, image=None, captions=None, if_test: bool = False):
         from ..hip import ops
         logit_scale = 4.0  # reference :333-334 (not logit_scale.exp())
+        training = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad and self.training
         with torch.no_grad():   # both "image" encoders are frozen (reference :762-765)
             if if_test or image is not None:
+                if not training and hasattr(self.image_encoder, "score"):
+                    # inference: ln_post + projection + normalise + x4.0 cosine logits are one kernel at the tower's tail
+                    return self.image_encoder.score(image, self.class_text_features(), logit_scale), None, None, None
                 image_features = self.image_encoder(image)
             else:
                 image_features = self.text_encoder(captions, None, if_embedding=False, if_sequence=False)
-        if torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad and self.training:
+        if training:
             from ..hip.autograd import CosineLogitsFunction
             prompts = self.prompt_learner()[0]
             text_features = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))

@@ -242,8 +242,160 @@ def main():
     except Exception as e:
         print("trainers/utils.py import failed:", repr(e))
     np.savez_compressed(os.path.join(OUT, "metrics_kat.npz"), **kat)
+    postprocess_goldens(np, torch, rng)
+    multicrop_goldens(np, torch)
     print("wrote", sorted(os.listdir(OUT)))
     return 0
+
+
+def _dedent_slice(src, start_anchor, end_anchor, include_end=False):
+    """The reference source text between two anchors, de-indented to column 0 (the lines are inline in a method)."""
+    import textwrap
+    a = src.index(start_anchor)
+    a = src.rfind("\n", 0, a) + 1
+    b = src.index(end_anchor, a)
+    if include_end:
+        b = src.index("\n", b) + 1
+    else:
+        b = src.rfind("\n", 0, b) + 1
+    return textwrap.dedent(src[a:b])
+
+
+def postprocess_goldens(np, torch, rng):
+    """the score post-processing that is INLINE in Caption_distill_double.test() (:614-618 adjust_predictions,
+    :632-636 the co-occurrence matrix from freq_stats.pkl, :654-660 the sliding-window aggregation) and the evaluator's
+    global/local merge (dassl/evaluation/evaluator.py:213-218).  The trainer module is not importable, so the reference's
+    own source lines are executed here as text slices (only `device='cuda'` is rewritten to 'cpu') on seeded scores and the
+    reference's real freq_stats.pkl; the outputs - data only - are the fixture."""
+    cdd = open(os.path.join(REF, "trainers", "Caption_distill_double.py")).read()
+    ns = {"torch": torch, "np": np}
+    exec(_dedent_slice(cdd, "def adjust_predictions(raw_predictions", "import pickle\n        result = pickle.load"), ns)
+    with open(os.path.join(REF, "freq_stats.pkl"), "rb") as f:
+        result = pickle.load(f)
+    out = {"freq.adj": np.asarray(result["adj"], dtype=np.float64), "freq.nums": np.asarray(result["nums"], dtype=np.float64)}
+    b, c = 16, 80
+    output = torch.from_numpy(rng.randn(b, c).astype(np.float32) * 0.3)
+    output_pos = torch.from_numpy(rng.randn(b, c).astype(np.float32) * 0.3)
+    # :632-636 (inside `if self.cfg.TEST.use_freq:`)
+    ns.update(result=result, output_pos=output_pos.clone())
+    code = _dedent_slice(cdd, "p = torch.tensor(result['adj'] / result['nums'][:, np.newaxis]", "output_pos = adjust_predictions(output_pos, p, 0.5)", True)
+    exec(code.replace("device='cuda'", "device='cpu'"), ns)
+    out.update({"n3.output_pos_in": output_pos.numpy(), "n3.p": ns["p"].numpy(), "n3.output_pos_adjusted": ns["output_pos"].numpy()})
+    # :654-660 - output_blocks [B, W, C] = scores of the W crops of each image (116 in the reference's comment; 3 scales here)
+    blocks = rng.randn(b, 116, c).astype(np.float32) * 0.3
+    blocks[:, :, 3] -= 2.0          # a class that never crosses the 0.3 threshold -> the min branch
+    blocks[:, :, 5] = 0.3           # alpha == threshold exactly: `>` is strict
+    ns.update(output_blocks=torch.from_numpy(blocks), output=output)
+    exec(_dedent_slice(cdd, "threshold = 0.3\n                    alpha = output_blocks.max(dim=1)[0]", "output_final = (1.4*s_ag + output)", True), ns)
+    out.update({"n2.output": output.numpy(), "n2.output_blocks": blocks, "n2.s_ag": ns["s_ag"].numpy(), "n2.output_final": ns["output_final"].numpy()})
+    # evaluator merge :213-218 (GL_merge_rate), executed on the two final score matrices
+    ev = open(os.path.join(REF, "Dassl.pytorch-master", "dassl", "evaluation", "evaluator.py")).read()
+
+    class _Cfg:
+        class TRAINER:
+            class Caption:
+                GL_merge_rate = 0.5
+    ns2 = {"preds": ns["output_final"], "preds_aux": ns["output_pos"], "self": type("S", (), {"cfg": _Cfg})()}
+    exec(_dedent_slice(ev, "tmp = self.cfg.TRAINER.Caption.GL_merge_rate", "preds_merge = preds.cpu().numpy() * tmp", True), ns2)
+    out["merge.preds_merge"] = ns2["preds_merge"]
+    out["merge.rate"] = np.float64(0.5)
+    np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
+    print("postprocess: s_ag", out["n2.s_ag"].shape, "adjusted", out["n3.output_pos_adjusted"].shape)
+
+
+def multicrop_goldens(np, torch):
+    """SURVEY 8f N2, the crop side: DatasetWrapperWithBlock._transform_image (dassl/data/data_manager.py:348-492) executed as a
+    source slice with recording stubs, so that every window's exact source-pixel footprint is known: `F.to_tensor(img0)`
+    returns a [2,h,w] coordinate grid instead of pixels, `F.pad` is torchvision 0.12.0's tensor pad semantics (the
+    reference's Docker base pytorch/pytorch:1.11.0 ships torchvision 0.12.0: a 4-sequence is (left, top, right, bottom),
+    transforms/functional_tensor.py `_parse_pad_padding` -> torch pad [left, right, top, bottom]), `tfm(block)` records
+    the block's shape, corner coordinates and coordinate checksums.  Plus PIL (Pillow) bicubic resize + centre crop +
+    ToTensor + Normalize of a few windows of a synthetic uint8 image - the test transform the reference applies to
+    every window (dassl/data/transforms/transforms.py:379-400: Resize(max(SIZE), bicubic) + CenterCrop + ToTensor + Normalize)."""
+    import textwrap
+    from PIL import Image
+    sys.path.insert(0, ROOT)
+    from leclip_amd import synth
+    dm = open(os.path.join(REF, "Dassl.pytorch-master", "dassl", "data", "data_manager.py")).read()
+    a = dm.index("class DatasetWrapperWithBlock")
+    a = dm.index("    def _transform_image(self, tfm, img0):", a)
+    b = dm.index("return img, img_blocks", a)
+    b = dm.index("\n", b) + 1
+    a = dm.rfind("\n", 0, a) + 1
+    # whitespace-only lines and the commented-out block at column 0 defeat de-indenting: blank them (comments carry no code)
+    fn_src = textwrap.dedent("\n".join(l if l.strip() and not l.lstrip().startswith("#") else "" for l in dm[a:b].split("\n")))
+
+    class FStub:
+        @staticmethod
+        def to_tensor(img0):
+            w, h = img0.size
+            yy, xx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+            return torch.stack([yy, xx]).double()
+
+        @staticmethod
+        def pad(img, padding, fill=0, padding_mode="constant"):
+            left, top, right, bottom = padding               # torchvision: (left, top, right, bottom)
+            return torch.nn.functional.pad(img[None], [left, right, top, bottom], mode=padding_mode)[0]
+
+        @staticmethod
+        def to_pil_image(block):
+            return block
+
+    def tfm(block):
+        if not torch.is_tensor(block):
+            return torch.zeros(8, dtype=torch.int64)
+        y, x = block[0].long(), block[1].long()
+        return torch.tensor([y.shape[0], y.shape[1], int(y[0, 0]), int(x[0, 0]), int(y[-1, -1]), int(x[-1, -1]), int(y.sum()), int(x.sum())])
+
+    ns = {"F": FStub, "torch": torch}
+    exec(fn_src, ns)
+    out = {}
+    sizes = [(480, 640), (375, 500), (427, 640), (500, 333), (224, 224), (97, 131)]
+    for (h, w) in sizes:
+        me = type("W", (), {"k_tfm": 1, "multi_scale": [2, 3, 4, 5]})()
+        img0 = type("I", (), {"size": (w, h)})()
+        _, blocks = ns["_transform_image"](me, tfm, img0)
+        for bs, blk in zip(me.multi_scale, blocks):
+            out[f"win.{h}x{w}.s{bs}"] = blk.numpy()
+    out["win.sizes"] = np.array(sizes)
+    print("multicrop windows per scale (480x640):", [out[f"win.480x640.s{k}"].shape[0] for k in (2, 3, 4, 5)])
+
+    # ---- the per-window transform on real pixels, with Pillow (version recorded) exactly as torchvision 0.12.0 drives it
+    h, w = 375, 500
+    src = synth.make_u8_image(h, w, seed=5)                       # [3, h, w] uint8
+    mean = np.array([0.48145466, 0.4578275, 0.40821073], dtype=np.float32)
+    std = np.array([0.26862954, 0.26130258, 0.27577711], dtype=np.float32)
+
+    def transform(crop_chw, size):
+        im = Image.fromarray(np.ascontiguousarray(crop_chw.transpose(1, 2, 0)), "RGB")
+        ww, hh = im.size
+        short, long_ = (ww, hh) if ww <= hh else (hh, ww)
+        new_short, new_long = size, int(size * long_ / short)                      # torchvision 0.12 _compute_resized_output_size
+        nw, nh = (new_short, new_long) if ww <= hh else (new_long, new_short)
+        if (ww, hh) != (nw, nh):
+            im = im.resize((nw, nh), Image.BICUBIC)
+        top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))     # CenterCrop
+        u8 = np.asarray(im)[top:top + size, left:left + size].transpose(2, 0, 1)
+        t = torch.from_numpy(np.ascontiguousarray(u8)).to(torch.float32).div(255)   # ToTensor
+        t = (t - torch.from_numpy(mean)[:, None, None]) / torch.from_numpy(std)[:, None, None]   # Normalize (sub_, div_)
+        return u8, t.numpy()
+
+    wins = [(0, 0, h, w, 0, 224), (0, 0, h, w, 0, 64), (10, 250, 187, 250, 0, 64), (100, 0, 125, 166, 0, 64), (0, 300, 375, 200, 0, 64),
+            (300, 420, 75, 80, 0, 64), (0, 0, 93, 125, 7, 64), (3, 40, 60, 31, 9, 64)]
+    for i, (y0, x0, bh, bw, pad_top, size) in enumerate(wins):
+        rows = np.arange(y0, y0 + bh) - pad_top                                      # padded-row -> source row, reflect (no edge repeat)
+        rows = np.where(rows < 0, -rows, rows)
+        rows = np.where(rows > h - 1, 2 * (h - 1) - rows, rows)
+        crop = src[:, rows][:, :, x0:min(x0 + bw, w)]
+        u8, f = transform(crop, size)
+        out[f"pil.{i}.u8"] = u8
+        out[f"pil.{i}.f32"] = f
+    out["pil.windows"] = np.array(wins, dtype=np.int64)
+    out["pil.src_hw"] = np.array([h, w])
+    out["pil.src_seed"] = np.int64(5)
+    import PIL
+    out["pil.version"] = np.array(PIL.__version__)
+    np.savez_compressed(os.path.join(OUT, "multicrop.npz"), **out)
 
 
 if __name__ == "__main__":

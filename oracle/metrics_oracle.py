@@ -47,15 +47,22 @@ def norm_logits_bce(pred: np.ndarray, targets: np.ndarray) -> float:
 
 def window_aggregate(global_logits: np.ndarray, window_logits: np.ndarray, threshold: float = 0.3, weight: float = 1.4) -> np.ndarray:
     """trainers/Caption_distill_double.py:654-660: alpha = max over windows, beta = min over windows,
-    gamma = alpha > threshold, s_ag = gamma*alpha + (1-gamma)*beta, final = 1.4*s_ag + global.  (Restated from the
-    inline code of ``test()``; that method is not callable in isolation, so this function is pinned by formula only.)"""
+    gamma = alpha > threshold, s_ag = gamma*alpha + (1-gamma)*beta, final = 1.4*s_ag + global.  Pinned: make_golden.py
+    executes those reference lines as a source slice on seeded scores (tests/golden/postprocess.npz)."""
     alpha, beta = window_logits.max(axis=1), window_logits.min(axis=1)
     gamma = (alpha > threshold).astype(window_logits.dtype)
     return weight * (gamma * alpha + (1 - gamma) * beta) + global_logits
 
 
 def cooccurrence_adjust(p: np.ndarray, adj: np.ndarray, nums: np.ndarray, weight: float = 0.5) -> np.ndarray:
-    """Caption_distill_double.py:614-618 + 632-636: M = adj / nums[:, None]; M /= M.sum(-1)[:, None]; p + weight * (p @ M)."""
+    """Caption_distill_double.py:614-618 + 632-636: M = adj / nums[:, None]; M /= M.sum(-1)[:, None]; p + weight * (p @ M).
+    Pinned the same way, on the reference's real freq_stats.pkl (values stored in the fixture)."""
     m = adj / nums[:, None]
     m = m / m.sum(-1)[:, None]
     return p + weight * (p @ m)
+
+
+def merge_global_local(preds: np.ndarray, preds_aux: np.ndarray, rate: float = 0.5) -> np.ndarray:
+    """dassl/evaluation/evaluator.py:213-218 (activate_func 'default_merge_aux'): preds * rate + preds_aux * (1 - rate)
+    with rate = cfg.TRAINER.Caption.GL_merge_rate."""
+    return np.asarray(preds) * rate + np.asarray(preds_aux) * (1 - rate)

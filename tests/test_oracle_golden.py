@@ -121,3 +121,36 @@ def test_average_precision_against_independent_implementation():
                 y[rng.integers(n)] = 1
             s = rng.permutation(n).astype(np.float64) / n            # distinct scores: no tie-order convention involved
             np.testing.assert_allclose(mo.average_precision(s, y), average_precision_score(y, s), rtol=0, atol=2e-8)   # (n_pos + 1e-8 in the denominator)
+
+
+def test_postprocess_against_reference_slices(golden_dir):
+    """N2 / N3 oracle restatements against the outputs of the reference's own source lines (executed by make_golden.py)."""
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    got = mo.window_aggregate(g["n2.output"], g["n2.output_blocks"])
+    np.testing.assert_allclose(got, g["n2.output_final"], atol=1e-6, rtol=0)
+    assert (g["n2.output_blocks"][:, :, 5].max(1) == np.float32(0.3)).all()       # alpha == threshold: strict `>` -> min branch
+    np.testing.assert_allclose(got[:, 5], 1.4 * g["n2.output_blocks"][:, :, 5].min(1) + g["n2.output"][:, 5], atol=1e-6)
+    adj = mo.cooccurrence_adjust(g["n3.output_pos_in"].astype(np.float64), g["freq.adj"], g["freq.nums"])
+    np.testing.assert_allclose(adj, g["n3.output_pos_adjusted"], atol=2e-6, rtol=0)
+    np.testing.assert_allclose(mo.merge_global_local(g["n2.output_final"], g["n3.output_pos_adjusted"], float(g["merge.rate"])),
+                               g["merge.preds_merge"], atol=1e-7, rtol=0)
+
+
+def test_multicrop_windows_and_transform(golden_dir):
+    """Window enumeration (oracle AND the product's enumerator) against the footprints recorded from the reference's
+    DatasetWrapperWithBlock code, and the numpy restatement of Pillow's resampler against Pillow's own output."""
+    from leclip_amd import multicrop
+    from oracle import multicrop_oracle as mc
+    g = np.load(os.path.join(golden_dir, "multicrop.npz"))
+    for (h, w) in g["win.sizes"]:
+        h, w = int(h), int(w)
+        mine = multicrop.enumerate_windows(h, w)
+        for bs, wo, wp in zip((2, 3, 4, 5), mc.windows(h, w), mine):
+            ref = g[f"win.{h}x{w}.s{bs}"]
+            assert np.array_equal(np.stack([mc.footprint(x, h) for x in wo]), ref), (h, w, bs)
+            assert wp.dtype == np.int32 and np.array_equal(wp, wo), (h, w, bs)      # product enumerator == oracle == reference
+    assert [len(x) for x in multicrop.enumerate_windows(480, 640)] == [40, 100, 164, 266]
+    src = synth.make_u8_image(int(g["pil.src_hw"][0]), int(g["pil.src_hw"][1]), seed=int(g["pil.src_seed"]))
+    for i, win in enumerate(g["pil.windows"]):
+        u8, f = mc.transform_window(src, win[:5], int(win[5]), multicrop.CLIP_PIXEL_MEAN, multicrop.CLIP_PIXEL_STD)
+        assert np.array_equal(u8, g[f"pil.{i}.u8"]) and np.array_equal(f, g[f"pil.{i}.f32"]), i
