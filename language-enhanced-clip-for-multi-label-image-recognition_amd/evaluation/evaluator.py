@@ -42,21 +42,34 @@ class MLClassification:
         self.reset()
 
     def reset(self):
-        self._scores, self._targets = [], []
+        self._scores, self._targets, self._scores_aux = [], [], []
 
-    def process(self, mo, gt, mo_aux=None):
+    def _act(self, mo):
         act = getattr(getattr(self.cfg, "TEST", None), "EVALUATOR_ACT", "default") if self.cfg is not None else "default"
         mo = torch.as_tensor(mo).float()
         if act == "softmax":
             mo = torch.softmax(mo, dim=1)
         elif act == "sigmoid":
             mo = torch.sigmoid(mo)
-        self._scores.append(mo.cpu().numpy())
+        return mo.cpu().numpy()
+
+    def process(self, mo, gt, mo_aux=None):
+        """Reference :197-205: ``mo`` global scores, ``mo_aux`` the local-branch scores (or None)."""
+        self._scores.append(self._act(mo))
         self._targets.append(torch.as_tensor(gt).cpu().numpy())
+        if mo_aux is not None:
+            self._scores_aux.append(self._act(mo_aux))
 
     def evaluate(self):
         scores = np.concatenate(self._scores, axis=0)
         targets = np.concatenate(self._targets, axis=0)
+        if len(self._scores_aux) > 0:
+            # reference :213-218: preds * GL_merge_rate + preds_aux * (1 - GL_merge_rate)
+            rate = 0.5
+            if self.cfg is not None:
+                rate = float(getattr(getattr(getattr(self.cfg, "TRAINER", None), "Caption", None), "GL_merge_rate", 0.5))
+            scores = scores * rate + np.concatenate(self._scores_aux, axis=0) * (1 - rate)
+        self.merged_scores = scores
         score = mAP(targets, scores)
         print(f"=> result\n* total: {len(scores):,}\n* mAP: {score:.4f}")
         return OrderedDict(mAP=score)

@@ -442,7 +442,8 @@ def crop_resize(src_u8: torch.Tensor, windows: torch.Tensor, size: int, mean, st
     _dev(src_u8, "src"), _dev(windows, "windows")
     if src_u8.dim() == 3:
         src_u8 = src_u8.unsqueeze(0)
-    assert src_u8.dtype == torch.uint8 and src_u8.is_contiguous() and src_u8.shape[1] == 3
+    src_u8 = src_u8.contiguous()
+    assert src_u8.dtype == torch.uint8 and src_u8.shape[1] == 3
     assert windows.dtype == torch.int32 and windows.is_contiguous() and windows.dim() == 2 and windows.shape[1] == 5
     b, _, h, w = src_u8.shape
     nw = windows.shape[0]

@@ -271,7 +271,7 @@ def make_u8_image(height: int, width: int, seed: int = 5, index: int = 0) -> np.
     g10, g11 = grid[:, iy + 1][:, :, ix], grid[:, iy + 1][:, :, ix + 1]
     wy0, wy1, wx0, wx1 = (16 - fy)[None, :, None], fy[None, :, None], (16 - fx)[None, None, :], fx[None, None, :]
     v = (wy0 * (wx0 * g00 + wx1 * g01) + wy1 * (wx0 * g10 + wx1 * g11)) // 256 + noise
-    return np.clip(v, 0, 255).astype(np.uint8)
+    return np.ascontiguousarray(np.clip(v, 0, 255).astype(np.uint8))
 
 
 def make_ctx(n_ctx: int, dim: int, seed: int = 0, name: str = "ctx", n_cls: Optional[int] = None) -> np.ndarray:

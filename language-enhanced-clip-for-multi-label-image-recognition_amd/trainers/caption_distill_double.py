@@ -246,26 +246,50 @@ class CustomCLIP(nn.Module):
 
 @TRAINER_REGISTRY.register()
 class Caption_distill_double:
-    """Trainer plug-in (reference :565-938) reduced to the hot path's callers: ``build_model``,
-    ``model_inference``, ``test``, ``load_model`` / ``save_model`` with the reference's checkpoint layout.
-    ``forward_backward`` is the prompt-tuning step on the text-tower backward kernels."""
+    """Trainer plug-in (reference :565-938 on dassl's TrainerBase / SimpleTrainer, dassl/engine/trainer.py:78-309) for the hot
+    path's callers: ``build_model`` (per-name models, prompt learner registered with its optimizer and scheduler),
+    ``train`` / ``before_epoch`` / ``run_epoch`` / ``after_epoch``, ``forward_backward`` (the prompt-tuning step, SURVEY.md
+    §8f N1, data-parallel with ONE flat all-reduce of the context gradients), ``test`` (multi-model loop, sliding-window
+    aggregation N2, co-occurrence modulation N3, global/local merge in the evaluator), ``save_model`` / ``load_model`` /
+    ``resume_model_if_exist`` in the reference's checkpoint layout.  One process per GPU; the process group, if any, is the
+    default one (RCCL on GPUs, gloo in the CPU tests)."""
 
-    def __init__(self, cfg, classnames: Optional[List[str]] = None, test_loader=None, evaluator=None):
+    def __init__(self, cfg, classnames: Optional[List[str]] = None, test_loader=None, evaluator=None, train_loader=None):
+        import torch.distributed as dist
         self.cfg = cfg
         self.check_cfg(cfg)
         self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+        self.rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if classnames is None:
             from ..datasets import coco_object_categories
             classnames = coco_object_categories
         self.classnames = list(classnames)
+        self.train_loader_x = train_loader
         self.test_loader = test_loader
+        self.val_loader = None
         self.evaluator = evaluator
-        self._models = OrderedDict()
-        self.epoch = 0
+        self._models, self._optims, self._scheds = OrderedDict(), OrderedDict(), OrderedDict()
+        self.start_epoch = self.epoch = 0
+        self.max_epoch = int(cfg.OPTIM.MAX_EPOCH)
+        self.output_dir = cfg.OUTPUT_DIR
+        self._cooc = None
         self.build_model()
 
+    # ------------------------------------------------------------------------------------------------ construction
     def check_cfg(self, cfg):
         assert cfg.TRAINER.Caption.PREC in ["fp16", "fp32", "amp", "bf16"]
+
+    def register_model(self, name, model, optim=None, sched=None):
+        """dassl/engine/trainer.py:80-106: what is registered is the PROMPT LEARNER (its state dict is the checkpoint)."""
+        assert name not in self._models, "Found duplicate model names"
+        self._models[name], self._optims[name], self._scheds[name] = model, optim, sched
+
+    def _model_names_cfg(self):
+        names = self.cfg.TEST.get("multi_model", False)      # reference :740 `names = cfg.TEST.multi_model` (a list of names)
+        if isinstance(names, (list, tuple)) and len(names) > 0:
+            return [str(n) for n in names]
+        return [str(self.cfg.TRAIN.get("MODEL_NAME", "default"))]
 
     def build_model(self):
         cfg = self.cfg
@@ -279,62 +303,193 @@ class Caption_distill_double:
             clip_pkg.convert_weights(clip_model, torch.bfloat16)
         if cfg.TRAIN.MODEL != "CustomCLIP":
             raise NotImplementedError(f"TRAIN.MODEL={cfg.TRAIN.MODEL}: only CustomCLIP wraps a ViT (reference :755-760)")
-        name = cfg.TRAIN.get("MODEL_NAME", "default")
-        model = CustomCLIP(cfg, self.classnames, clip_model)
-        for pname, param in model.named_parameters():       # reference :762-765
-            param.requires_grad_("prompt_learner." in pname and "prompt_learner_m." not in pname)
-        model.to(self.device)
-        model.eval()
-        self._models[name] = model
-        setattr(self, f"model_{name}", model)
-        return model
+        import copy
+        names = self._model_names_cfg()
+        for i, name in enumerate(names):
+            model = CustomCLIP(cfg, self.classnames, clip_model if i == len(names) - 1 else copy.deepcopy(clip_model))
+            for pname, param in model.named_parameters():       # reference :762-765
+                param.requires_grad_("prompt_learner." in pname and "prompt_learner_m." not in pname)
+            if cfg.MODEL.get("INIT_WEIGHTS", ""):
+                sd = torch.load(cfg.MODEL.INIT_WEIGHTS, map_location="cpu")
+                model.prompt_learner.load_state_dict(sd.get("state_dict", sd), strict=False)
+            model.to(self.device)
+            self._sync_prompt_learner(model)
+            model.eval()
+            setattr(self, f"model_{name}", model)
+            optim, sched = self._build_optim_for(model)
+            self.register_model(name, model.prompt_learner, optim, sched)
+        self.optim, self.sched = self._optims[names[0]], self._scheds[names[0]]
+        return getattr(self, f"model_{names[0]}")
 
-    def get_model_names(self):
-        return list(self._models.keys())
+    def _sync_prompt_learner(self, model):
+        """World > 1: every rank must tune and score the SAME prompts.  The learnable context is drawn from torch's RNG
+        (reference :128-151), which is not seeded identically on every rank unless SEED is set, so rank 0's parameters and
+        buffers are broadcast once after construction - what DDP's constructor does for the reference (:786-787)."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        with torch.no_grad():
+            for t in list(model.prompt_learner.parameters()) + list(model.prompt_learner.buffers()):
+                if t.is_floating_point() or t.dtype in (torch.int64, torch.int32):
+                    dist.broadcast(t.data, src=0)
+            if getattr(model, "ema", False):
+                model.copy_params()
+        model._text_cache = None
+
+    def _build_optim_for(self, model):
+        """SGD on the prompt learner only + cosine schedule with a constant-LR warm-up epoch (dassl/optim/optimizer.py:13-137,
+        lr_scheduler.py:10-154 with the shipped OPTIM keys)."""
+        o = self.cfg.OPTIM
+        params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
+        optim = torch.optim.SGD(params, lr=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY)
+        sched = torch.optim.lr_scheduler.CosineAnnealingLR(optim, T_max=max(int(o.MAX_EPOCH), 1))
+        self._base_lr = o.LR
+        if o.WARMUP_EPOCH > 0 and o.WARMUP_TYPE == "constant":
+            for g in optim.param_groups:
+                g["lr"] = o.WARMUP_CONS_LR
+        return optim, sched
+
+    def build_optim(self):
+        """(Re)build optimizer and scheduler of the first model - kept for callers that construct the trainer and then
+        change OPTIM keys; build_model already registered a pair."""
+        name = self.get_model_names()[0]
+        self._optims[name], self._scheds[name] = self._build_optim_for(getattr(self, f"model_{name}"))
+        self.optim, self.sched = self._optims[name], self._scheds[name]
+        return self.optim
+
+    def get_model_names(self, names=None):
+        real = list(self._models.keys())
+        if names is None:
+            return real
+        names = [names] if isinstance(names, str) else list(names)
+        for n in names:
+            assert n in real
+        return names
+
+    def set_model_mode(self, mode="train", names=None):
+        for name in self.get_model_names(names):
+            model = getattr(self, f"model_{name}")
+            if mode == "train":
+                model.train()
+            elif mode in ("test", "eval"):
+                model.eval()
+            else:
+                raise KeyError(mode)
 
     def model_inference(self, input, name):
         """Reference :567-568: ``self.model_<name>(input, if_test=True)``."""
-        return self._models[name](input, if_test=True)
+        return getattr(self, f"model_{name}")(input, if_test=True)
 
     def parse_batch_test(self, batch):
-        return batch["img"].to(self.device, non_blocking=True), batch["label"]
+        """Reference :899-... returns (input, label, input_blocks): ``img_blocks`` is the per-scale list of window batches
+        a DatasetWrapperWithBlock item carries (data_manager.py:336-341); None without TEST.multi_scale."""
+        blocks = batch.get("img_blocks") if isinstance(batch, dict) else None
+        if blocks is not None:
+            blocks = [b.to(self.device, non_blocking=True) for b in blocks]
+        return batch["img"].to(self.device, non_blocking=True), batch["label"], blocks
 
     def parse_batch_train(self, batch):
         return batch["img"].to(self.device), batch["label"].to(self.device)
 
-    def build_optim(self):
-        """SGD on the prompt learner only + cosine schedule with a constant-LR warm-up epoch (dassl/optim/optimizer.py:13-137,
-        lr_scheduler.py:10-154 with the shipped OPTIM keys)."""
+    # ------------------------------------------------------------------------------------------------ training loop
+    def update_lr(self, names=None):
+        """Per-epoch schedule step (dassl/engine/trainer.py:214-219) with the constant-LR warm-up of lr_scheduler.py:41-82."""
         o = self.cfg.OPTIM
-        model = self._models[self.get_model_names()[0]]
-        params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
-        self.optim = torch.optim.SGD(params, lr=o.LR, momentum=o.MOMENTUM, weight_decay=o.WEIGHT_DECAY)
-        self.sched = torch.optim.lr_scheduler.CosineAnnealingLR(self.optim, T_max=max(int(o.MAX_EPOCH), 1))
-        self._base_lr = o.LR
-        if o.WARMUP_EPOCH > 0 and o.WARMUP_TYPE == "constant":
-            for g in self.optim.param_groups:
-                g["lr"] = o.WARMUP_CONS_LR
-        return self.optim
+        self._lr_epoch = getattr(self, "_lr_epoch", 0) + 1
+        for name in self.get_model_names(names):
+            optim, sched = self._optims[name], self._scheds[name]
+            if optim is None:
+                continue
+            if self._lr_epoch == o.WARMUP_EPOCH and o.WARMUP_TYPE == "constant":
+                for g in optim.param_groups:
+                    g["lr"] = self._base_lr
+            elif self._lr_epoch > o.WARMUP_EPOCH:
+                sched.step()
 
-    def update_lr(self):
-        o = self.cfg.OPTIM
-        self.epoch += 1
-        if self.epoch == o.WARMUP_EPOCH and o.WARMUP_TYPE == "constant":
-            for g in self.optim.param_groups:
-                g["lr"] = self._base_lr
-        elif self.epoch > o.WARMUP_EPOCH:
-            self.sched.step()
+    def train(self, start_epoch=None, max_epoch=None):
+        """Generic training loop (dassl/engine/trainer.py:255-264)."""
+        self.start_epoch = self.start_epoch if start_epoch is None else start_epoch
+        self.max_epoch = self.max_epoch if max_epoch is None else max_epoch
+        self.before_train()
+        last = {}
+        for self.epoch in range(self.start_epoch, self.max_epoch):
+            self.before_epoch()
+            last = self.run_epoch()
+            self.after_epoch()
+        self.after_train()
+        return last
+
+    def before_train(self):
+        """dassl/engine/trainer.py:375-388: resume from OUTPUT_DIR when RESUME is set."""
+        directory = self.cfg.get("RESUME", "") or ""
+        if directory:
+            self.start_epoch = self.resume_model_if_exist(directory)
+        self.time_start = time.time()
+
+    def after_train(self):
+        print(f"Finished training ({time.time() - self.time_start:.1f} s)")
+
+    def before_epoch(self):
+        """Reference :571-574: rank 0 announces the epoch; the distributed sampler is re-seeded with it."""
+        if self.rank == 0:
+            print(f"before_epoch: {self.epoch}")
+        sampler = getattr(self.train_loader_x, "sampler", None)
+        if sampler is not None and hasattr(sampler, "set_epoch"):
+            sampler.set_epoch(self.epoch)
+        elif hasattr(self.train_loader_x, "set_epoch"):
+            self.train_loader_x.set_epoch(self.epoch)
+
+    def run_epoch(self):
+        """dassl/engine/trainer.py:575-612 (TrainerX.run_epoch): one pass over train_loader_x, then the schedule step."""
+        assert self.train_loader_x is not None, "no training loader was given to the trainer"
+        self.set_model_mode("train")
+        last = {}
+        for self.batch_idx, batch in enumerate(self.train_loader_x):
+            last = self.forward_backward(batch)
+        self.update_lr()
+        if self.rank == 0 and last:
+            print(f"epoch [{self.epoch + 1}/{self.max_epoch}] loss {last['loss']:.4f} lr {self.optim.param_groups[0]['lr']:.3e}")
+        return last
+
+    def after_epoch(self):
+        """Reference :576-587: rank 0 only - checkpoint every CHECKPOINT_FREQ epochs and after the last one."""
+        if self.rank == 0:
+            print(f"after_epoch: {self.epoch}")
+            last_epoch = (self.epoch + 1) == self.max_epoch
+            freq = int(self.cfg.TRAIN.CHECKPOINT_FREQ)
+            meet_checkpoint_freq = (self.epoch + 1) % freq == 0 if freq > 0 else False
+            if (meet_checkpoint_freq or last_epoch) and self.output_dir:
+                self.save_model(self.epoch, self.output_dir)
+        if self.world > 1:
+            import torch.distributed as dist
+            dist.barrier()      # nobody evaluates or resumes before the checkpoint is on disk
+
+    def _allreduce_grads(self, params):
+        """Data-parallel tuning step: mean of the context gradients over ranks, ONE collective on one flat fp32 buffer
+        (3 x [16, 512] = 96 KiB for the generic context; DDP's bucketed all-reduce in the reference, :786-787)."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in params]
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(self.world)
+        o = 0
+        for p, g in zip(params, grads):
+            n = g.numel()
+            p.grad = flat[o:o + n].view_as(g).to(g.dtype)
+            o += n
 
     def forward_backward(self, batch):
         """One prompt-tuning step (reference :789-897, fp32 branch).  ``batch["img"]`` is either tokenised captions
         [B,77] int64 - the reference's texts-as-images feed, ``model(None, captions)`` - or images [B,3,R,R]
         (CoOp-style tuning on the frozen image tower, BASELINE config 3).  Loss: ``ranking_loss(scale_=1, margin_=1)``
-        for LOSSFUNC == "double_ranking" (:806-808), BCE-with-logits for "bce" (trainers/utils.py:21-23)."""
+        for LOSSFUNC == "double_ranking" (:806-808), BCE-with-logits for "bce" (trainers/utils.py:21-23).  Under
+        WORLD_SIZE > 1 the batch is this rank's shard and the gradients are averaged over ranks before the step."""
         from .utils import norm_logits_BCEloss, ranking_loss
-        if getattr(self, "optim", None) is None:
-            self.build_optim()
         name = self.get_model_names()[0]
-        model = self._models[name]
+        model = getattr(self, f"model_{name}")
+        optim = self._optims[name]
         model.train()
         inp, label = self.parse_batch_train(batch)
         if inp.dtype in (torch.int64, torch.int32):
@@ -350,37 +505,131 @@ class Caption_distill_double:
             raise NotImplementedError(f"loss function {lf} not implemented")
         if not torch.isfinite(loss):
             raise FloatingPointError("Loss is infinite or NaN!")   # dassl/engine/trainer.py:224-226
-        self.optim.zero_grad()
+        optim.zero_grad()
         loss.backward()
-        self.optim.step()
+        self._allreduce_grads([p for g in optim.param_groups for p in g["params"]])
+        optim.step()
         model._text_cache = None
         return {f"loss_{lf}": loss.item(), "loss": loss.item()}
 
+    # ------------------------------------------------------------------------------------------------------- testing
+    def cooccurrence_matrix(self):
+        """Row-normalised conditional co-occurrence matrix of reference :632-634 from ``freq_stats.pkl`` ({'adj', 'nums'},
+        path in cfg.TEST.freq_stats, default ./freq_stats.pkl as in the reference :620)."""
+        if self._cooc is None:
+            import pickle
+            from ..hip import ops
+            path = self.cfg.TEST.get("freq_stats", "freq_stats.pkl")
+            if not osp.isfile(path):
+                raise FileNotFoundError(f'TEST.use_freq needs the co-occurrence statistics at "{path}" (set TEST.freq_stats)')
+            with open(path, "rb") as f:
+                result = pickle.load(f)
+            self._cooc = ops.cooccurrence_matrix(result["adj"], result["nums"]).to(self.device)
+        return self._cooc
+
+    def _score_blocks(self, input_blocks, name):
+        """Reference :639-652: every scale's windows [B, W_s, 3, R, R] go through the model as a [B*W_s, ...] batch (in chunks
+        of DATALOADER.TEST.BATCH_SIZE windows); returns global scores [B, sum W_s, C] and local scores or None."""
+        chunk = max(int(self.cfg.DATALOADER.TEST.BATCH_SIZE), 1)
+        outs, outs_pos = [], []
+        for blk in input_blocks:
+            b, w = blk.shape[0], blk.shape[1]
+            flat = blk.reshape(b * w, *blk.shape[2:])
+            res = [self.model_inference(flat[s:s + chunk].contiguous(), name) for s in range(0, b * w, chunk)]
+            outs.append(torch.cat([r[0] for r in res]).reshape(b, w, -1))
+            if res[0][1] is not None:
+                outs_pos.append(torch.cat([r[1] for r in res]).reshape(b, w, -1))
+        return torch.cat(outs, dim=1), (torch.cat(outs_pos, dim=1) if outs_pos else None)
+
     @torch.no_grad()
     def test(self, split=None, mode="test"):
-        """Score every batch of the test loader with every registered model and feed the evaluator
-        (reference :589-732 without the sliding-window / co-occurrence post-processing, rows N2/N3)."""
-        assert self.test_loader is not None and self.evaluator is not None
+        """Reference :589-732.  Per batch and model: global scores (+ local scores when the model has a local branch);
+        TEST.use_freq: co-occurrence modulation of the local scores (:632-636, N3); when the batch carries ``img_blocks``
+        (TEST.multi_scale): window scores aggregated as 1.4 * s_ag + output (:654-668, N2); the evaluator merges global
+        and local scores (GL_merge_rate).  Returns the first metric, like the reference (:726)."""
+        from ..hip import ops
+        assert self.evaluator is not None
+        self.set_model_mode("eval")
         self.evaluator.reset()
-        name = self.get_model_names()[0]
-        for batch in self.test_loader:
-            images, labels = self.parse_batch_test(batch)
-            logits = self.model_inference(images, name)[0]
-            self.evaluator.process(logits.float().cpu(), labels)
-        return self.evaluator.evaluate()
+        if split is None:
+            split = self.cfg.TEST.SPLIT
+        data_loader = self.val_loader if (split == "val" and self.val_loader is not None) else self.test_loader
+        assert data_loader is not None, "no test loader was given to the trainer"
+        names = self.get_model_names()
+        if mode == "test" and len(names) > 1:
+            # reference :697-700: evaluating with several models needs a fusion strategy, which it never added
+            raise NotImplementedError("Can not use multi model when evaluating, fuse strategy need to be added")
+        use_freq = bool(self.cfg.TEST.get("use_freq", False))
+        for batch in data_loader:
+            input, label, input_blocks = self.parse_batch_test(batch)
+            for name in names:
+                res = self.model_inference(input, name)
+                output, output_pos = res[0].float(), (res[1].float() if res[1] is not None else None)
+                if use_freq and output_pos is not None:
+                    output_pos = ops.cooccurrence_adjust(output_pos, self.cooccurrence_matrix(), 0.5)
+                if mode == "test" and input_blocks is not None:
+                    output_blocks, output_pos_blocks = self._score_blocks(input_blocks, name)
+                    output_final = ops.window_aggregate(output, output_blocks, threshold=0.3, weight=1.4)
+                    output_pos_final = output_pos
+                    if output_pos_blocks is not None:
+                        b, w, c = output_pos_blocks.shape
+                        if use_freq:
+                            output_pos_blocks = ops.cooccurrence_adjust(output_pos_blocks.reshape(b * w, c), self.cooccurrence_matrix(), 0.5).reshape(b, w, c)
+                        output_pos_final = ops.window_aggregate(output_pos, output_pos_blocks, threshold=0.3, weight=1.4)
+                else:
+                    output_final, output_pos_final = output, output_pos
+            self.evaluator.process(output_final.cpu(), label, None if output_pos_final is None else output_pos_final.cpu())
+        results = self.evaluator.evaluate()
+        return list(results.values())[0]
 
-    # ------------------------------------------------------------------ checkpoints (dassl/utils/torchtools.py:27-82)
-    def save_model(self, epoch: int, directory: str, is_best: bool = False):
-        for name, model in self._models.items():
-            sd = OrderedDict((k, v.detach().cpu()) for k, v in model.prompt_learner.state_dict().items())
+    # ------------------------------------------------------------------ checkpoints (dassl/utils/torchtools.py:27-82, 126-165)
+    def save_model(self, epoch: int, directory: str, is_best: bool = False, model_name: str = ""):
+        """dassl/engine/trainer.py:119-143 + torchtools.save_checkpoint: ``<dir>/<name>/model.pth.tar-<epoch+1>`` holding the
+        prompt learner's state dict, ``epoch + 1``, the optimizer's and the scheduler's state, plus the ``checkpoint``
+        pointer file.  Rank 0 writes; other ranks return (all ranks hold identical prompts after the gradient all-reduce)."""
+        if self.rank != 0:
+            return
+        import shutil
+        for name in self.get_model_names():
+            sd = OrderedDict((k[7:] if k.startswith("module.") else k, v.detach().cpu()) for k, v in self._models[name].state_dict().items())
+            optim, sched = self._optims.get(name), self._scheds.get(name)
+            state = {"state_dict": sd, "epoch": epoch + 1, "optimizer": None if optim is None else optim.state_dict(),
+                     "scheduler": None if sched is None else sched.state_dict(), "lr_epoch": getattr(self, "_lr_epoch", 0)}
             folder = osp.join(directory, name)
             os.makedirs(folder, exist_ok=True)
-            fpath = osp.join(folder, f"model.pth.tar-{epoch}")
-            torch.save({"state_dict": sd, "epoch": epoch, "optimizer": None, "scheduler": None}, fpath)
-            with open(osp.join(folder, "checkpoint"), "w") as f:
+            fpath = osp.join(folder, model_name or f"model.pth.tar-{epoch + 1}")
+            torch.save(state, fpath)
+            print(f'Checkpoint saved to "{fpath}"')
+            with open(osp.join(folder, "checkpoint"), "w+") as f:
                 f.write(osp.basename(fpath) + "\n")
             if is_best:
-                torch.save({"state_dict": sd, "epoch": epoch}, osp.join(folder, "model-best.pth.tar"))
+                shutil.copy(fpath, osp.join(folder, "model-best.pth.tar"))
+
+    def resume_model_if_exist(self, directory: str) -> int:
+        """dassl/engine/trainer.py:145-170 + torchtools.resume_from_checkpoint: follow the ``checkpoint`` pointer, restore the
+        prompt learner, the optimizer and the scheduler, return the epoch to continue from."""
+        names = self.get_model_names()
+        if any(not osp.exists(osp.join(directory, name, "checkpoint")) for name in names):
+            print("No checkpoint found, train from scratch")
+            return 0
+        print(f'Found checkpoint in "{directory}". Will resume training')
+        start_epoch = 0
+        for name in names:
+            folder = osp.join(directory, name)
+            with open(osp.join(folder, "checkpoint")) as f:
+                fpath = osp.join(folder, f.readlines()[0].strip("\n"))
+            print(f'Loading checkpoint from "{fpath}"')
+            ck = torch.load(fpath, map_location="cpu")
+            self._models[name].load_state_dict(ck["state_dict"], strict=False)
+            if self._optims[name] is not None and ck.get("optimizer") is not None:
+                self._optims[name].load_state_dict(ck["optimizer"])
+            if self._scheds[name] is not None and ck.get("scheduler") is not None:
+                self._scheds[name].load_state_dict(ck["scheduler"])
+            self._lr_epoch = int(ck.get("lr_epoch", ck["epoch"]))
+            start_epoch = int(ck["epoch"])
+            getattr(self, f"model_{name}")._text_cache = None
+            print(f"Previous epoch: {start_epoch}")
+        return start_epoch
 
     def load_model(self, directory: str, epoch: Optional[int] = None):
         """Reference :906-938: read ``<dir>/<name>/model.pth.tar[-E]``, drop ``token_prefix`` / ``token_suffix``
@@ -388,7 +637,7 @@ class Caption_distill_double:
         if not directory:
             print("Note that load_model() is skipped as no pretrained model is given")
             return
-        for name, model in self._models.items():
+        for name in self.get_model_names():
             model_file = "model.pth.tar" if epoch is None else f"model.pth.tar-{epoch}"
             model_path = osp.join(directory, name, model_file)
             if not osp.exists(model_path):
@@ -398,5 +647,5 @@ class Caption_distill_double:
             for key in ("token_prefix", "token_suffix", "token_suffix_nocls"):
                 state_dict.pop(key, None)
             print(f'Loading weights to {name} from "{model_path}" (epoch = {checkpoint.get("epoch")})')
-            model.prompt_learner.load_state_dict(state_dict, strict=False)
-            model._text_cache = None
+            self._models[name].load_state_dict(state_dict, strict=False)
+            getattr(self, f"model_{name}")._text_cache = None

@@ -71,3 +71,88 @@ def test_single_process_is_identity():
     x = torch.randn(6, 3, 4, 4)
     sc = parallel.ShardedScorer(_score)
     assert sc.world == 1 and torch.equal(sc.score_local(x), _score(x)) and torch.equal(parallel.all_gather_rows(_score(x)), _score(x))
+
+
+# ------------------------------------------------------------------------------ data-parallel prompt tuning (N > 1 ranks)
+def _trainer_cfg():
+    from leclip_amd.config import get_cfg_default
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "OPTIM.MAX_EPOCH", "2", "OPTIM.WARMUP_EPOCH", "0"])
+    return cfg
+
+
+def _tune_worker(rank, world, port, outdir, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    from leclip_amd.registry import build_trainer
+    from leclip_amd.train_caption import SyntheticCaptionLoader
+    torch.manual_seed(100 + rank)            # ranks start from DIFFERENT random prompts (SEED = -1 in the reference's default cfg)
+    tr = build_trainer(_trainer_cfg())
+    model = tr.model_default
+    ctx_after_build = model.prompt_learner.ctx.detach().clone()
+    # the gradient exchange: every rank contributes rank-dependent gradients, all end with the mean, in one flat collective
+    params = [p for p in model.prompt_learner.parameters() if p.requires_grad]
+    for i, p in enumerate(params):
+        p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
+    tr._allreduce_grads(params)
+    want = [(1 + 2) / 2.0 * (i + 1) for i in range(len(params))]
+    grads_ok = all(bool(torch.allclose(p.grad, torch.full_like(p, w))) for p, w in zip(params, want))
+    # rank-sharded caption order: same permutation on every rank, disjoint contiguous slices
+    caps = torch.arange(23 * 77).view(23, 77)
+    loader = SyntheticCaptionLoader(caps, torch.zeros(23, 80), batch_size=5, seed=3, rank=rank, world=world)
+    loader.set_epoch(4)
+    idx = loader.indices()
+    # checkpoints: rank 0 only
+    tr.save_model(0, outdir)
+    dist.barrier()
+    wrote = os.path.exists(os.path.join(outdir, "default", "model.pth.tar-1"))
+    out_q.put((rank, ctx_after_build.numpy(), grads_ok, idx.numpy(), wrote, len(params)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_tuning_plumbing_world2(tmp_path):
+    """WORLD_SIZE = 2 (gloo): prompts broadcast from rank 0 at construction (ranks draw different random contexts otherwise),
+    ONE flat all-reduce gives every rank the mean gradient, the caption sampler hands each rank a disjoint slice of the same
+    permutation, and only rank 0 writes checkpoints."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tune_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, ctx0, g0, i0, w0, n0), (_, ctx1, g1, i1, w1, n1) = res
+    assert np.array_equal(ctx0, ctx1) and g0 and g1 and n0 == n1 == 6
+    assert w0 and w1 and sorted(os.listdir(tmp_path / "default")) == ["checkpoint", "model.pth.tar-1"]
+    both = np.concatenate([i0, i1])
+    assert len(i0) == len(i1) == 12 and set(both.tolist()) == set(range(23)) and len(set(i0.tolist()) & set(i1.tolist())) <= 1
+
+
+def test_resume_restores_optimizer_and_scheduler(tmp_path):
+    """save_model / resume_model_if_exist (dassl/engine/trainer.py:119-170, torchtools.py:27-82, 126-165): the prompt learner, SGD
+    momentum buffers and the cosine schedule position survive a restart; the epoch to continue from is returned."""
+    from leclip_amd.registry import build_trainer
+    torch.manual_seed(0)
+    tr = build_trainer(_trainer_cfg())
+    params = [p for p in tr.model_default.prompt_learner.parameters() if p.requires_grad]
+    for step in range(3):
+        for p in params:
+            p.grad = torch.ones_like(p) * (step + 1)
+        tr.optim.step()
+    tr.update_lr()
+    tr.save_model(0, str(tmp_path))
+    lr_saved = tr.optim.param_groups[0]["lr"]
+    torch.manual_seed(1)
+    tr2 = build_trainer(_trainer_cfg())
+    assert not torch.equal(tr2.model_default.prompt_learner.ctx, tr.model_default.prompt_learner.ctx)
+    assert tr2.resume_model_if_exist(str(tmp_path)) == 1
+    assert torch.equal(tr2.model_default.prompt_learner.ctx, tr.model_default.prompt_learner.ctx)
+    b1 = tr.optim.state_dict()["state"][0]["momentum_buffer"]
+    b2 = tr2.optim.state_dict()["state"][0]["momentum_buffer"]
+    assert torch.equal(b1, b2) and tr2.optim.param_groups[0]["lr"] == lr_saved and tr2.sched.last_epoch == tr.sched.last_epoch
+    assert build_trainer(_trainer_cfg()).resume_model_if_exist(str(tmp_path / "nothing_here")) == 0

@@ -220,3 +220,144 @@ def test_train_caption_entry_point_tunes_saves_and_evaluates(ops, tmp_path):
                               "DATALOADER.TEST.BATCH_SIZE", "32"])
     assert (tmp_path / "default" / "model.pth.tar-2").exists()
     assert out is not None and 0.0 <= float(out["mAP"]) <= 100.0
+
+
+def test_cfg3_prompt_tuning_step_at_size(ops, golden_dir):
+    """BASELINE configs[2] AT SIZE: ViT-B/16, 16 learnable context tokens, B = 512 images in bf16 through the frozen image tower,
+    text tower forward + backward w.r.t. the context, BCE loss.  Oracle: fp32 CPU image features of the same 512 images
+    (text tower with autograd through the oracle).  bf16 activations move the logits by ~1e-2 (scale 4), so the loss agrees to
+    a few 1e-3 and the gradient direction to cos >= 0.97; one SGD step through trainer.forward_backward then lowers the loss."""
+    from oracle import clip_oracle as co
+    arch = synth.VIT_B16
+    sd = synth.make_state_dict(arch, seed=0, dist="cond")
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    toks_ctx = torch.from_numpy(t["tokens_ctx16"])
+    ctx0 = torch.from_numpy(synth.make_ctx(16, 512, seed=0))
+    n = 512
+    img = torch.from_numpy(synth.make_images(n, 224, seed=1234))
+    labels = torch.from_numpy((synth.uniform(3, "tune.labels", (n, 80), 0, 1) < 0.04).astype(np.float32))
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        feats = torch.cat([co.encode_image(img[i:i + 32], sd) for i in range(0, n, 32)])
+    ctx = ctx0.clone().requires_grad_(True)
+    prefix, suffix = co.prompt_buffers(toks_ctx, sd, 16)
+    txt = co.text_encoder(co.prompt_learner_forward(ctx, prefix, suffix), toks_ctx, sd)
+    l_ref = torch.nn.functional.binary_cross_entropy_with_logits(co.cosine_logits(feats, txt, 4.0), labels)
+    l_ref.backward()
+    g_ref = ctx.grad.clone()
+    l_hip, g_hip, z_hip, _ = _hip_ctx_grad(arch, sd, ctx0, img, labels, "bce", torch.bfloat16)
+    rel = float((g_hip.double() - g_ref.double()).norm() / g_ref.double().norm())
+    cos = float(torch.nn.functional.cosine_similarity(g_hip.flatten().double(), g_ref.flatten().double(), dim=0))
+    print(f"cfg3 B=512 bf16: loss {l_hip:.5f} vs oracle {float(l_ref):.5f}, grad rel err {rel:.3f}, cos {cos:.5f}")
+    assert z_hip.shape == (n, 80) and abs(l_hip - float(l_ref)) <= 5e-3 * max(1.0, abs(float(l_ref)))
+    assert cos >= 0.97 and rel <= 0.3
+
+
+def _grad_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from leclip_amd import parallel
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    parallel.init_from_env(backend="gloo")       # two ranks share the one GPU of the test box; gloo carries the device tensors
+    torch.manual_seed(50 + rank)                 # different random prompts per rank until rank 0's are broadcast
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "OPTIM.LR", "0.0", "OPTIM.WARMUP_EPOCH", "0", "OPTIM.WEIGHT_DECAY", "0.0"])
+    tr = build_trainer(cfg)
+    toks = torch.from_numpy(np.load(os.path.join(os.path.dirname(__file__), "golden", "tokens_coco80.npz"))["tokens_photo"][:16])
+    labels = torch.zeros(16, 80)
+    labels[torch.arange(16), torch.arange(16)] = 1.0
+    lo, hi = parallel.shard_bounds(16, rank, world)
+    out = tr.forward_backward({"img": toks[lo:hi], "label": labels[lo:hi]})
+    model = tr.model_default
+    q.put((rank, model.prompt_learner.ctx.detach().cpu().numpy(), model.prompt_learner.ctx.grad.detach().cpu().numpy(), out["loss"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradients_equal_full_batch(ops, golden_dir):
+    """Data-parallel prompt tuning, world size 2 (both ranks on cuda:0, gloo transport): after the flat all-reduce each rank's
+    context gradient equals the single-process gradient of the whole batch, and both ranks hold rank 0's prompts."""
+    import socket
+    import torch.multiprocessing as mp
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=600) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (_, c0, g0, l0), (_, c1, g1, l1) = res
+    assert np.array_equal(c0, c1) and np.array_equal(g0, g1)
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "OPTIM.LR", "0.0", "OPTIM.WARMUP_EPOCH", "0", "OPTIM.WEIGHT_DECAY", "0.0"])
+    tr = build_trainer(cfg)
+    with torch.no_grad():
+        tr.model_default.prompt_learner.ctx.copy_(torch.from_numpy(c0))
+    toks = torch.from_numpy(np.load(os.path.join(golden_dir, "tokens_coco80.npz"))["tokens_photo"][:16])
+    labels = torch.zeros(16, 80)
+    labels[torch.arange(16), torch.arange(16)] = 1.0
+    full = tr.forward_backward({"img": toks, "label": labels})
+    g_full = tr.model_default.prompt_learner.ctx.grad.detach().cpu().numpy()
+    np.testing.assert_allclose(g0, g_full, atol=2e-5 * float(np.abs(g_full).max()), rtol=0)
+    assert abs(0.5 * (l0 + l1) - full["loss"]) <= 1e-4 * max(1.0, abs(full["loss"]))
+
+
+def test_trainer_test_with_multi_scale_windows(ops, golden_dir, tmp_path):
+    """Caption_distill_double.test() (reference :589-732) wired end to end on the tiny model: raw uint8 images -> MultiCropper
+    (global view + every sliding window, on the device) -> model on the global view and on every window -> window aggregation
+    1.4 * s_ag + output (N2) -> evaluator mAP; against the same steps composed by hand with the numpy oracles."""
+    import pickle
+    from leclip_amd import multicrop
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_evaluator, build_trainer
+    from oracle import metrics_oracle as mo
+    torch.manual_seed(0)
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    with open(tmp_path / "freq_stats.pkl", "wb") as f:
+        pickle.dump({"adj": g["freq.adj"], "nums": g["freq.nums"]}, f)
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)",
+                         "TRAINER.Caption.PREC", "fp32", "DATALOADER.TEST.BATCH_SIZE", "64", "TEST.multi_scale", "[2, 3]",
+                         "TEST.use_freq", "True", "TEST.freq_stats", str(tmp_path / "freq_stats.pkl")])
+    cropper = multicrop.MultiCropper(size=32, multi_scale=(2, 3))
+    n, bsz = 6, 3
+    raw = np.stack([synth.make_u8_image(97, 131, seed=21, index=i) for i in range(n)])
+    labels = (synth.uniform(5, "ms.labels", (n, 80), 0, 1) < 0.2).astype(np.int64)
+
+    def loader():
+        for s in range(0, n, bsz):
+            img, blocks = cropper(torch.from_numpy(raw[s:s + bsz]).to(DEV))
+            yield {"img": img, "label": torch.from_numpy(labels[s:s + bsz]), "img_blocks": blocks}
+
+    class Loader:
+        def __iter__(self):
+            return loader()
+
+    ev = build_evaluator(cfg)
+    tr = build_trainer(cfg, evaluator=ev, test_loader=Loader())
+    got = tr.test(mode="test")
+    model = tr.model_default
+    outs = []
+    with torch.no_grad():
+        for batch in loader():
+            o = model(batch["img"], if_test=True)[0].cpu().numpy()
+            ob = np.concatenate([model(b.reshape(-1, 3, 32, 32), if_test=True)[0].reshape(b.shape[0], b.shape[1], -1).cpu().numpy()
+                                 for b in batch["img_blocks"]], axis=1)
+            assert ob.shape[1] == sum(len(w) for w in multicrop.enumerate_windows(97, 131, (2, 3)))
+            outs.append(mo.window_aggregate(o, ob))
+    from leclip_amd.evaluation import mAP
+    want = mAP(labels, np.concatenate(outs))
+    assert abs(got - want) < 1e-9 and 0.0 < got <= 100.0
+    plain = tr.test(mode="train")          # mode != "test": no window aggregation (reference :637)
+    assert plain != got

@@ -490,6 +490,30 @@ def test_vit_l14_336_shapes_against_oracle(ops, golden_dir, dt):
         assert np.array_equal(lpi.cpu().numpy().argmax(1), ref.argmax(1))
 
 
+def test_cfg5_vit_l14_336_full_depth(ops, golden_dir):
+    """BASELINE configs[4] at FULL depth (24 + 12 blocks, 577 tokens, width 1024 / 768) in fp16 - the precision that config
+    names - on 8 images x 80 prompts against the fp32 CPU oracle: streaming attention, patch-14 embedding, the large-K
+    GEMMs and the fused tail at width 1024 / embed 768."""
+    from oracle import clip_oracle as co
+    arch = synth.VIT_L14_336
+    sd = synth.make_state_dict(arch, seed=3, dist="cond")
+    m = _build(arch, 3, "cond", torch.float16)
+    img = torch.from_numpy(synth.make_images(8, 336, seed=9))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    toks = torch.from_numpy(t["tokens_photo"])
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref = co.clip_forward(img, toks, sd).numpy()
+        lpi, _ = m(img.to(DEV), toks.to(DEV))
+    lpi = lpi.cpu().numpy()
+    err = float(np.abs(lpi - ref).max())
+    print(f"ViT-L/14@336 full depth fp16: max|dlogit| {err:.3e} at scale {float(sd['logit_scale'].exp()):.1f}, top1 agree "
+          f"{(lpi.argmax(1) == ref.argmax(1)).mean():.3f}")
+    assert lpi.shape == (8, 80) and err <= 4e-2          # cosine error <= 2.8e-3 at scale 14.3
+    ok = _margin_ok(ref, 4e-2)
+    assert np.array_equal(lpi.argmax(1)[ok], ref.argmax(1)[ok])
+
+
 def test_train_caption_eval_entry_point(ops):
     from leclip_amd import train_caption
     out = train_caption.main(["--eval-only", "--trainer", "Caption_distill_double", "--backbone", "tiny", "--num-images", "48",
