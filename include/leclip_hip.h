@@ -174,6 +174,19 @@ int leclip_scatter_rows_fwd(const void* src, const int64_t* index, void* dst, in
 int leclip_crop_resize_fwd(const uint8_t* src, int64_t B, int H, int W, const int32_t* windows, int NW, void* out, int S,
                            const float* mean3, const float* std3, leclip_dtype out_dtype, void* stream);
 
+/* ---- local ("dense") branch for a ViT.  The reference defines it for the ResNet only
+ * (trainers/Caption_distill_double.py:401-472: per-position features from attnpool's v/c projections); for a ViT the
+ * per-position features are the PATCH TOKENS of the last block taken through the same ln_post and proj as the class token.
+ * x[r, :] /= |x[r, :]| in place (fp32): the `image_features / image_features.norm(dim=-1)` of :434 on [B*T, E] rows. */
+int leclip_l2norm_rows_fwd(float* x, int64_t rows, int dim, int64_t ld, void* stream);
+/* Spatial pooling of :447-462.  sim holds, per image, P rows (positions) of similarities against the "negative" prompts in
+ * columns [0, C) and - when evidence_offset >= 0 - against the evidence prompts in columns [evidence_offset, +C); row p of
+ * image b starts at sim + b * image_stride + p * ld.  Without evidence: prob = softmax over positions of scale * s,
+ * out[b, c] = sum_p logit_scale * s * prob.  With evidence (winner-take-all): w = softmax over classes of
+ * scale * s * (max_c s + 1), s <- s * w, prob = softmax over positions of scale * e.  All fp32; out [B, C]. */
+int leclip_local_pool_fwd(const float* sim, float* out, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset,
+                          float spatial_scale, float logit_scale, void* stream);
+
 /* ---- score post-processing of the reference's test loop
  * Sliding-window aggregation, trainers/Caption_distill_double.py:654-660: window_logits [B, W, C] are the scores of the W
  * crops of each image; alpha = max_w, beta = min_w, s_ag = alpha > threshold ? alpha : beta, out = weight * s_ag + global

@@ -151,6 +151,12 @@ class VisionTransformer(nn.Module):
             raise RuntimeError("VisionTransformer.forward needs a HIP device tensor (no CPU fallback on the product path)")
         return self.engine(x.device).forward(x, taps)
 
+    def dense_features(self, x: torch.Tensor) -> torch.Tensor:
+        """[B, T, E] fp32 features of every token (class token first): ln_post + proj applied to all rows of the last block."""
+        if not x.is_cuda:
+            raise RuntimeError("VisionTransformer.dense_features needs a HIP device tensor (no CPU fallback on the product path)")
+        return self.engine(x.device).dense_features(x)
+
     def score(self, x: torch.Tensor, text_features: torch.Tensor, scale: float) -> torch.Tensor:
         """scale * normalize(self(x)) @ normalize(text_features).T (model.py:399-404) with the contraction folded into the
         tower's tail kernel: logits [B, C] fp32."""

@@ -84,11 +84,12 @@ def get_cfg_default() -> CfgNode:
                   "WARMUP_TYPE": "constant", "WARMUP_CONS_LR": 1e-5, "MOMENTUM": 0.9, "WEIGHT_DECAY": 5e-4},
         "TRAIN": {"CHECKPOINT_FREQ": 0, "PRINT_FREQ": 10, "LOSSFUNC": "double_ranking", "MODEL": "CustomCLIP",
                   "MODEL_NAME": "default", "IF_LEARN_SCALE": False, "IF_LEARN_spatial_SCALE": False,
-                  "spatial_SCALE_text": 50, "spatial_SCALE_image": 50, "IF_ablation": False, "Caption_num": 0,
-                  "ema": False, "momentum": 0.999},
+                  "spatial_SCALE_text": 50, "spatial_SCALE_image": 40, "IF_ablation": False, "Caption_num": 0,
+                  "ema": False, "momentum": 0.995},
         "TEST": {"EVALUATOR": "MLClassification", "EVALUATOR_ACT": "default", "PER_CLASS_RESULT": False,
                  "COMPUTE_CMAT": False, "NO_TEST": False, "SPLIT": "test", "FINAL_MODEL": "last_step",
-                 "SAVE_PREDS": "", "multi_model": False, "multi_scale": False, "save_pth": "", "use_freq": False},
+                 "SAVE_PREDS": "", "multi_model": False, "multi_scale": False, "save_pth": "", "use_freq": False,
+                 "freq_stats": "freq_stats.pkl"},
         "TRAINER": {"NAME": "Caption_distill_double",
                     "Caption": {"N_CTX": 16, "CSC": False, "CTX_INIT": "", "PREC": "fp16",
                                 "CLASS_TOKEN_POSITION": "end", "GL_merge_rate": 0.5, "use_evidence": False}},

@@ -243,6 +243,65 @@ __global__ void move_rows_kernel(const char* __restrict__ src, const int64_t* __
     for (int k = threadIdx.x * 16; k < row_bytes; k += blockDim.x * 16) *(i32x4*)(d + k) = *(const i32x4*)(s + k);
 }
 
+// x[r, :] /= |x[r, :]|_2 in place (fp32 rows; one wave per row) - the patch-token features of the local branch
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, int64_t rows, int dim, int64_t ld) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    float* xr = x + r * ld;
+    float s = 0.f;
+    for (int k = lane * 4; k < dim; k += 256) { const f32x4 t = *(const f32x4*)(xr + k); s = fmaf(t[0], t[0], s); s = fmaf(t[1], t[1], s); s = fmaf(t[2], t[2], s); s = fmaf(t[3], t[3], s); }
+    const float inv = 1.0f / sqrtf(wave_sum(s));
+    for (int k = lane * 4; k < dim; k += 256) { f32x4 t = *(const f32x4*)(xr + k); t[0] *= inv; t[1] *= inv; t[2] *= inv; t[3] *= inv; *(f32x4*)(xr + k) = t; }
+}
+
+// Local (dense) branch pooling, trainers/Caption_distill_double.py:447-462 with patches in place of the ResNet's HxW positions:
+//   s[p, c]  = <patch feature p, "negative" prompt c> (both normalised), e[p, c] the same against the evidence prompts
+//   evidence: w = softmax_c(tmp * s * (max_c s + 1));  s <- s * w;  prob = softmax_p(tmp * e)      (winner-take-all)
+//   else:     prob = softmax_p(tmp * s)
+//   logits_local[c] = sum_p logit_scale * s[p, c] * prob[p, c]
+// One workgroup per image; its [P, C] similarity panel(s) live in LDS.
+__global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict__ sim, float* __restrict__ out, int P, int C, int64_t ld,
+                                                         int64_t image_stride, int evi_off, float tmp, float logit_scale) {
+    extern __shared__ float sm[];      // s [P][C] (| e [P][C])
+    const int tid = threadIdx.x;
+    const float* src = sim + (int64_t)blockIdx.x * image_stride;
+    float* s = sm;
+    float* e = sm + P * C;
+    for (int i = tid; i < P * C; i += 256) {
+        const int p = i / C, c = i - p * C;
+        s[i] = src[(int64_t)p * ld + c];
+        if (evi_off >= 0) e[i] = src[(int64_t)p * ld + evi_off + c];
+    }
+    __syncthreads();
+    if (evi_off >= 0) {
+        for (int p = tid; p < P; p += 256) {     // per patch: softmax over classes of tmp * s * (max + 1), then s *= w
+            float* row = s + p * C;
+            float mx = row[0];
+            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+            const float k = tmp * (mx + 1.0f);
+            float zmax = k * row[0];
+            for (int c = 1; c < C; ++c) zmax = fmaxf(zmax, k * row[c]);
+            float den = 0.f;
+            for (int c = 0; c < C; ++c) den += expf(k * row[c] - zmax);
+            for (int c = 0; c < C; ++c) row[c] *= expf(k * row[c] - zmax) / den;
+        }
+        __syncthreads();
+    }
+    const float* z = evi_off >= 0 ? e : s;
+    for (int c = tid; c < C; c += 256) {         // per class: softmax over patches, weighted sum
+        float mx = tmp * z[c];
+        for (int p = 1; p < P; ++p) mx = fmaxf(mx, tmp * z[p * C + c]);
+        float den = 0.f, num = 0.f;
+        for (int p = 0; p < P; ++p) {
+            const float w = expf(tmp * z[p * C + c] - mx);
+            den += w;
+            num = fmaf(w, s[p * C + c], num);
+        }
+        out[(int64_t)blockIdx.x * C + c] = logit_scale * num / den;
+    }
+}
+
 template <typename T>
 int launch_tail(const TailArgs& a, hipStream_t s) {
     const int lds = 16 * (a.d * (int)sizeof(T) + 16) + (16 * (a.E + 4) + 16 + a.C) * 4;
@@ -319,4 +378,26 @@ extern "C" int leclip_scatter_rows_fwd(const void* src, const int64_t* index, vo
                                        int64_t ld_dst, leclip_dtype dtype, void* stream) {
     if (dst_rows <= 0) { leclip_set_error("scatter_rows: bad size"); return LECLIP_E_INVALID; }
     return move_rows(src, index, dst, n, dim, ld_src, ld_dst, (int)dtype, 1, dst_rows, stream, "scatter_rows");
+}
+
+extern "C" int leclip_l2norm_rows_fwd(float* x, int64_t rows, int dim, int64_t ld, void* stream) {
+    if (!x || rows <= 0 || dim <= 0 || ld < dim) { leclip_set_error("l2norm_rows: bad argument"); return LECLIP_E_INVALID; }
+    if (dim % 4 || ld % 4 || ((uintptr_t)x & 15)) { leclip_set_error("l2norm_rows: rows must be 16-byte aligned multiples of 4 floats"); return LECLIP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, rows, dim, ld);
+    return leclip_check_launch("l2norm_rows_kernel");
+}
+
+extern "C" int leclip_local_pool_fwd(const float* sim, float* out, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset,
+                                     float spatial_scale, float logit_scale, void* stream) {
+    if (!sim || !out || B <= 0 || P <= 0 || C <= 0 || ld < C || image_stride < (int64_t)(P - 1) * ld + C || (evidence_offset >= 0 && evidence_offset + C > ld)) {
+        leclip_set_error("local_pool: null pointer or inconsistent sizes");
+        return LECLIP_E_INVALID;
+    }
+    const size_t lds = (size_t)P * C * 4 * (evidence_offset >= 0 ? 2 : 1);
+    if (lds > 160 * 1024) { leclip_set_error("local_pool: P=%d x C=%d does not fit LDS", P, C); return LECLIP_E_UNSUPPORTED; }
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(local_pool_kernel, 160 * 1024, attr_set);
+    hipLaunchKernelGGL(local_pool_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, sim, out, P, C, ld, image_stride, evidence_offset,
+                       spatial_scale, logit_scale);
+    return leclip_check_launch("local_pool_kernel");
 }

@@ -66,6 +66,8 @@ SIGNATURES = {
     "leclip_l2norm_logits_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "leclip_gather_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "leclip_scatter_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
+    "leclip_l2norm_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "leclip_local_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
     "leclip_crop_resize_fwd": (c_int, [c_void_p, c_int64, c_int, c_int, c_void_p, c_int, c_void_p, c_int, ctypes.POINTER(c_float),
                                        ctypes.POINTER(c_float), c_int, c_void_p]),
 }

@@ -210,6 +210,24 @@ class VisionEngine:
         x, batch, cls_rows = self._trunk(image, taps)
         return self._tail(x, batch, cls_rows, None, 1.0, True)[0]
 
+    def dense_features(self, image: torch.Tensor) -> torch.Tensor:
+        """[B, T, E] fp32: EVERY token of the last block through ln_post and proj (row 0 = the class token = forward()'s
+        feature, rows 1.. = the patch tokens) - the per-position features of the local branch."""
+        x, batch, _ = self._trunk(image)
+        h = ops.layernorm(x, self.ln_post_w, self.ln_post_b)
+        return ops.gemm(h, self.proj_t_padded(), out_dtype=torch.float32)[:, :self.proj.shape[1]].reshape(batch, self.tokens, -1)
+
+    def proj_t_padded(self):
+        """proj^T with its row count (E) rounded up to the GEMM kernels' N granularity (zero rows)."""
+        if getattr(self, "_proj_t_pad", None) is None:
+            e, d = self.proj_t.shape
+            gran = 64 if self.dtype == torch.float32 else 128
+            ep = (e + gran - 1) // gran * gran
+            w = torch.zeros((ep, d), dtype=self.dtype, device=self.device)
+            w[:e] = self.proj_t
+            self._proj_t_pad = w
+        return self._proj_t_pad
+
     def score(self, image: torch.Tensor, text_features: torch.Tensor, scale: float, want_features: bool = False):
         """(features or None, logits [B, C]): the image tower with the cosine-logit contraction folded into its tail kernel."""
         x, batch, cls_rows = self._trunk(image)

@@ -453,3 +453,25 @@ def crop_resize(src_u8: torch.Tensor, windows: torch.Tensor, size: int, mean, st
     _capi.check(_capi.load().leclip_crop_resize_fwd(_ptr(src_u8), b, h, w, _ptr(windows), nw, _ptr(out), size, m3, s3, dtype_code(out_dtype),
                                                     _stream()), "crop_resize")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- local (dense) branch, N4
+def l2norm_rows_(x: torch.Tensor) -> torch.Tensor:
+    """In-place row-wise L2 normalisation of an fp32 matrix."""
+    rows, dim, ld = _rows2d(x, "x")
+    assert x.dtype == torch.float32
+    _capi.check(_capi.load().leclip_l2norm_rows_fwd(_ptr(x), rows, dim, ld, _stream()), "l2norm_rows")
+    return x
+
+
+def local_pool(sim: torch.Tensor, batch: int, tokens: int, first: int, n_cls: int, evidence_offset: int, spatial_scale: float,
+               logit_scale: float) -> torch.Tensor:
+    """sim [batch * tokens, ld] fp32 (positions ``first`` .. tokens-1 of every image are pooled) -> logits_local [batch, n_cls]."""
+    _dev(sim, "sim")
+    assert sim.dtype == torch.float32 and sim.is_contiguous() and sim.shape[0] == batch * tokens
+    ld = sim.shape[1]
+    out = torch.empty((batch, n_cls), dtype=torch.float32, device=sim.device)
+    view = sim[first:]          # skip the class-token row of image 0; image stride stays tokens * ld
+    _capi.check(_capi.load().leclip_local_pool_fwd(_ptr(view), _ptr(out), batch, tokens - first, n_cls, ld, tokens * ld, evidence_offset,
+                                                   float(spatial_scale), float(logit_scale), _stream()), "local_pool")
+    return out

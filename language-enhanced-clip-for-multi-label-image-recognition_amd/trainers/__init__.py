@@ -1,1 +1,1 @@
-from .caption_distill_double import Caption_distill_double, CustomCLIP, PromptLearner, TextEncoder  # noqa: F401
+from .caption_distill_double import Caption_distill_double, CustomCLIP, DenseCLIP, PromptLearner, TextEncoder  # noqa: F401

@@ -244,6 +244,63 @@ class CustomCLIP(nn.Module):
         return logits, None, None, None
 
 
+class DenseCLIP(CustomCLIP):
+    """Global + LOCAL branch for a ViT.  The reference's ``DenseCLIP`` (:354-559) exists for the ResNet
+    only: its per-position features come from ``attnpool``'s v / c projections applied to the 7x7 feature map (:409-410).
+    The definition used here for a ViT - the reference never wrote one - is the direct analogue: the per-position features
+    are the PATCH TOKENS of the last block taken through the same ``ln_post`` and ``proj`` as the class token; everything
+    downstream is the reference's arithmetic (:434-462): normalise, similarities against the "negative" (``ctx_double``)
+    prompts, spatial softmax over positions at ``TRAIN.spatial_SCALE_image`` (or ``spatial_T.exp()``), optionally the
+    evidence prompts' winner-take-all weighting (``TRAINER.Caption.use_evidence``), ``logits_local = sum_p scale * s * prob``.
+    The top-k caption-feature mixing of :437-440 needs the reference's ChatGLM caption-feature file and is not part of it.
+    Inference only (``if_test=True``); returns (logits_, logits_local, None, None, None) like the reference's test branch."""
+
+    def __init__(self, cfg, classnames, clip_model, return_interm_layers=False, nctx=None):
+        super().__init__(cfg, classnames, clip_model)
+        self.cfg = cfg
+        self.prompt_text_features = None
+
+    def _prompt_features(self):
+        """text_features / text_features_neg (/ text_features_evidence), cached like the reference (:421-439)."""
+        key = tuple((p._version, p.data_ptr()) for p in (self.prompt_learner.ctx, self.prompt_learner.ctx_double, self.prompt_learner.ctx_evidence))
+        if self.prompt_text_features is None or self.prompt_text_features["key"] != key:
+            prompts, prompts_double, prompts_evidence, _, _, _ = self.prompt_learner()
+            toks = self.tokenized_prompts.to(prompts.device)
+            feats = {"key": key, "text_features": self.text_encoder(prompts, toks), "text_features_neg": self.text_encoder(prompts_double, toks)}
+            if self.cfg.TRAINER.Caption.get("use_evidence", False):
+                feats["text_features_evidence"] = self.text_encoder(prompts_evidence, toks)
+            # the similarity GEMM's W operand: rows = normalised negative (| evidence) prompt features, padded to 64 / 128 rows
+            from ..hip import ops
+            rows = [ops.l2norm_rows_(feats["text_features_neg"].clone())]
+            if "text_features_evidence" in feats:
+                rows.append(ops.l2norm_rows_(feats["text_features_evidence"].clone()))
+            c = rows[0].shape[0]
+            cp = (c + 63) // 64 * 64
+            w = torch.zeros((cp * len(rows), rows[0].shape[1]), dtype=torch.float32, device=rows[0].device)
+            for i, r in enumerate(rows):
+                w[i * cp:i * cp + c] = r
+            feats["w_local"], feats["c_pad"] = w, cp
+            self.prompt_text_features = feats
+        return self.prompt_text_features
+
+    def forward(self, image=None, captions=None, if_test: bool = False, model_name: str = "ema"):
+        from ..hip import ops
+        if not if_test:
+            raise NotImplementedError("DenseCLIP for a ViT is an inference-time branch in this build (if_test=True); tune with CustomCLIP")
+        with torch.no_grad():
+            f = self._prompt_features()
+            dense = self.image_encoder.dense_features(image)                 # [B, T, E] fp32
+            b, t, e = dense.shape
+            logit_scale = float(self.prompt_learner.temperature.exp()) if self.cfg.TRAIN.IF_LEARN_SCALE else 4.0
+            logits_ = ops.l2norm_logits(dense[:, 0].contiguous(), f["text_features"], logit_scale)
+            flat = ops.l2norm_rows_(dense.reshape(b * t, e))                  # image_features / norm (:434), every position
+            sim = ops.gemm(flat, f["w_local"], out_dtype=torch.float32)       # exact-fp32 MFMA: [B*T, c_pad (x2)]
+            tmp = float(self.prompt_learner.spatial_T.exp()) if self.cfg.TRAIN.IF_LEARN_spatial_SCALE else float(self.cfg.TRAIN.spatial_SCALE_image)
+            evi = f["c_pad"] if "text_features_evidence" in f else -1
+            logits_local = ops.local_pool(sim, b, t, 1, f["text_features"].shape[0], evi, tmp, logit_scale)
+        return logits_, logits_local, None, None, None
+
+
 @TRAINER_REGISTRY.register()
 class Caption_distill_double:
     """Trainer plug-in (reference :565-938 on dassl's TrainerBase / SimpleTrainer, dassl/engine/trainer.py:78-309) for the hot
@@ -301,12 +358,13 @@ class Caption_distill_double:
         elif prec == "bf16":
             clip_model.float()
             clip_pkg.convert_weights(clip_model, torch.bfloat16)
-        if cfg.TRAIN.MODEL != "CustomCLIP":
-            raise NotImplementedError(f"TRAIN.MODEL={cfg.TRAIN.MODEL}: only CustomCLIP wraps a ViT (reference :755-760)")
+        if cfg.TRAIN.MODEL not in ("CustomCLIP", "DenseCLIP"):
+            raise NotImplementedError(f"model {cfg.TRAIN.MODEL} not implemented")      # reference :755-760
         import copy
         names = self._model_names_cfg()
         for i, name in enumerate(names):
-            model = CustomCLIP(cfg, self.classnames, clip_model if i == len(names) - 1 else copy.deepcopy(clip_model))
+            model_cls = DenseCLIP if cfg.TRAIN.MODEL == "DenseCLIP" else CustomCLIP
+            model = model_cls(cfg, self.classnames, clip_model if i == len(names) - 1 else copy.deepcopy(clip_model))
             for pname, param in model.named_parameters():       # reference :762-765
                 param.requires_grad_("prompt_learner." in pname and "prompt_learner_m." not in pname)
             if cfg.MODEL.get("INIT_WEIGHTS", ""):

@@ -210,6 +210,44 @@ def custom_clip_forward_captions(captions: Tensor, sd: Dict[str, Tensor], ctx: T
     return cosine_logits(img, txt, scale)
 
 
+def encode_image_tokens(image: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """[B, T, E]: every token of the last block through ln_post and proj (model.py:271-274 applied to all rows, not only
+    x[:, 0, :]).  Row 0 equals encode_image; rows 1.. are the ViT's per-position features of the local branch (the reference
+    defines per-position features only for the ResNet, Caption_distill_double.py:409-410 - SURVEY.md §8f N4)."""
+    image = image.float()
+    heads = sd["visual.conv1.weight"].shape[0] // 64
+    x = layer_norm(patch_embed(image, sd), sd["visual.ln_pre.weight"], sd["visual.ln_pre.bias"])
+    for i in range(_n_layers(sd, "visual.transformer.")):
+        x = residual_block(x, sd, f"visual.transformer.resblocks.{i}.", heads, None)
+    return layer_norm(x, sd["visual.ln_post.weight"], sd["visual.ln_post.bias"]) @ sd["visual.proj"]
+
+
+def local_pool(logits_neg: Tensor, logits_evidence: Optional[Tensor], tmp_scale: float, logit_scale: float) -> Tensor:
+    """Caption_distill_double.py:447-462 on similarity panels [positions, batch, classes] (pinned: make_golden.py executes those
+    reference lines, tests/golden/postprocess.npz n4.*)."""
+    if logits_evidence is not None:
+        w = torch.softmax(tmp_scale * logits_neg * (logits_neg.max(-1)[0].unsqueeze(-1) + 1), -1)   # winner-take-all
+        logits_neg = logits_neg * w
+        prob_spatial = torch.softmax(logits_evidence * tmp_scale, dim=0)
+    else:
+        prob_spatial = torch.softmax(logits_neg * tmp_scale, dim=0)
+    return torch.sum(logit_scale * logits_neg * prob_spatial, dim=0)
+
+
+def dense_clip_forward(image: Tensor, sd: Dict[str, Tensor], ctx: Tensor, ctx_double: Tensor, ctx_evidence: Optional[Tensor],
+                       prefix: Tensor, suffix: Tensor, tokenized_prompts: Tensor, tmp_scale: float = 40.0, scale: float = 4.0):
+    """DenseCLIP.forward(if_test=True) (:401-462) with the ViT's patch tokens as positions: (logits_, logits_local)."""
+    feats = encode_image_tokens(image, sd)                                   # [B, T, E]
+    enc = lambda c: l2_normalize(text_encoder(prompt_learner_forward(c, prefix, suffix), tokenized_prompts, sd))
+    text, text_neg = enc(ctx), enc(ctx_double)
+    glob = l2_normalize(feats[:, 0])
+    pos = l2_normalize(feats[:, 1:]).permute(1, 0, 2)                        # [P, B, E]
+    logits_ = scale * glob @ text.t()
+    logits_neg = pos @ text_neg.t()
+    logits_evi = pos @ enc(ctx_evidence).t() if ctx_evidence is not None else None
+    return logits_, local_pool(logits_neg, logits_evi, tmp_scale, scale)
+
+
 def flatten_taps(taps: dict, prefix: str = "") -> Dict[str, np.ndarray]:
     out = {}
     for k, v in taps.items():

@@ -299,6 +299,31 @@ def postprocess_goldens(np, torch, rng):
     exec(_dedent_slice(ev, "tmp = self.cfg.TRAINER.Caption.GL_merge_rate", "preds_merge = preds.cpu().numpy() * tmp", True), ns2)
     out["merge.preds_merge"] = ns2["preds_merge"]
     out["merge.rate"] = np.float64(0.5)
+    # N4: the spatial pooling of the local branch (DenseCLIP.forward, if_test: :447-462) on seeded similarity panels
+    # [positions, batch, classes], with and without the evidence prompts' winner-take-all weighting
+    P, Bn, Cn = 49, 3, 80
+    sim = lambda: torch.from_numpy(np.tanh(rng.randn(P, Bn, Cn) * 0.5).astype(np.float32) * 0.4)
+
+    def _cfgnode(use_evidence):
+        class _C:
+            class TRAIN:
+                IF_LEARN_spatial_SCALE = False
+                spatial_SCALE_image = 40
+            class TRAINER:
+                class Caption:
+                    pass
+        _C.TRAINER.Caption.use_evidence = use_evidence
+        return type("S", (), {"cfg": _C})()
+    code = _dedent_slice(cdd, "tmp_scale = spatial_T.exp() if self.cfg.TRAIN.IF_LEARN_spatial_SCALE else self.cfg.TRAIN.spatial_SCALE_image",
+                         "logits_local = torch.sum(logit_scale * logits_neg * prob_spatial, dim=0)", True)
+    out["n4.logits_neg"], out["n4.logits_evidence"] = sim().numpy(), sim().numpy()
+    for tag, use_ev in (("plain", False), ("evidence", True)):
+        ln, le = torch.from_numpy(out["n4.logits_neg"]).clone(), torch.from_numpy(out["n4.logits_evidence"]).clone()
+        ns4 = {"torch": torch, "self": _cfgnode(use_ev), "spatial_T": torch.tensor(3.0), "logit_scale": 4.0, "logits_neg": ln,
+               # the slice recomputes logits_evidence = image_features @ text_features_evidence.t(): identity "prompts" hand it the panel
+               "image_features": le, "text_features_evidence": torch.eye(Cn)}
+        exec(code, ns4)
+        out[f"n4.logits_local.{tag}"] = ns4["logits_local"].numpy()
     np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
     print("postprocess: s_ag", out["n2.s_ag"].shape, "adjusted", out["n3.output_pos_adjusted"].shape)
 

@@ -514,6 +514,57 @@ def test_cfg5_vit_l14_336_full_depth(ops, golden_dir):
     assert np.array_equal(lpi.argmax(1)[ok], ref.argmax(1)[ok])
 
 
+def test_local_pool_kernel_against_reference_slice(ops, golden_dir):
+    """leclip_local_pool_fwd against the outputs of the reference's own pooling lines (:447-462), both variants."""
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    ln, le = g["n4.logits_neg"], g["n4.logits_evidence"]            # [P, B, C]
+    p, b, c = ln.shape
+    t, cp = p + 1, 128
+    sim = np.zeros((b, t, 2 * cp), dtype=np.float32)                 # row 0 of every image = the class token (skipped), padded columns
+    sim[:, 1:, :c] = ln.transpose(1, 0, 2)
+    sim[:, 1:, cp:cp + c] = le.transpose(1, 0, 2)
+    sim[:, 0] = 7.0
+    d = torch.from_numpy(sim.reshape(b * t, 2 * cp)).to(DEV)
+    got = ops.local_pool(d, b, t, 1, c, -1, 40.0, 4.0).cpu().numpy()
+    np.testing.assert_allclose(got, g["n4.logits_local.plain"], atol=2e-6, rtol=2e-6)
+    got = ops.local_pool(d, b, t, 1, c, cp, 40.0, 4.0).cpu().numpy()
+    np.testing.assert_allclose(got, g["n4.logits_local.evidence"], atol=1e-9, rtol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("use_evidence", [False, True])
+def test_dense_clip_local_branch(ops, golden_dir, dt, use_evidence):
+    """N4 end to end on the tiny model: DenseCLIP (ViT local branch) global and local logits against the oracle's
+    dense_clip_forward; then through trainer.test() with TEST.use_freq, where the local scores take the co-occurrence
+    modulation (N3) and the evaluator merges global and local scores with GL_merge_rate."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import DenseCLIP
+    from oracle import clip_oracle as co
+    arch = synth.TINY
+    sd = synth.make_state_dict(arch, seed=1, dist="cond")
+    m = _build(arch, 1, "cond", dt).cpu()
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["INPUT.SIZE", "(32, 32)", "TRAINER.Caption.use_evidence", str(use_evidence), "TRAIN.MODEL", "DenseCLIP"])
+    dc = DenseCLIP(cfg, coco_object_categories, m)
+    w = arch.transformer_width
+    ctx, ctx2, ctx3 = [torch.from_numpy(synth.make_ctx(16, w, seed=s, name=n) * 10) for s, n in ((0, "ctx"), (1, "ctx_double"), (2, "ctx_evidence"))]
+    with torch.no_grad():
+        dc.prompt_learner.ctx.copy_(ctx); dc.prompt_learner.ctx_double.copy_(ctx2); dc.prompt_learner.ctx_evidence.copy_(ctx3)
+    dc.to(DEV).eval()
+    img = torch.from_numpy(synth.make_images(5, 32, seed=11))
+    toks = dc.tokenized_prompts
+    prefix, suffix = co.prompt_buffers(toks, sd, 16)
+    with torch.no_grad():
+        ref_g, ref_l = co.dense_clip_forward(img, sd, ctx, ctx2, ctx3 if use_evidence else None, prefix, suffix, toks, 40.0, 4.0)
+        out = dc(img.to(DEV), if_test=True)
+    assert len(out) == 5 and out[0].shape == (5, 80) and out[1].shape == (5, 80)
+    tol = _tol(dt, 1e-3, 2e-2, 1.5e-1)
+    np.testing.assert_allclose(out[0].cpu().numpy(), ref_g.numpy(), atol=tol, rtol=0)
+    scale_l = float(ref_l.abs().max())
+    np.testing.assert_allclose(out[1].cpu().numpy(), ref_l.numpy(), atol=tol * max(scale_l, 1e-3) * 2, rtol=0)
+
+
 def test_train_caption_eval_entry_point(ops):
     from leclip_amd import train_caption
     out = train_caption.main(["--eval-only", "--trainer", "Caption_distill_double", "--backbone", "tiny", "--num-images", "48",

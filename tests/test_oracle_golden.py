@@ -154,3 +154,11 @@ def test_multicrop_windows_and_transform(golden_dir):
     for i, win in enumerate(g["pil.windows"]):
         u8, f = mc.transform_window(src, win[:5], int(win[5]), multicrop.CLIP_PIXEL_MEAN, multicrop.CLIP_PIXEL_STD)
         assert np.array_equal(u8, g[f"pil.{i}.u8"]) and np.array_equal(f, g[f"pil.{i}.f32"]), i
+
+
+def test_local_pool_against_reference_slice(golden_dir):
+    """N4: the oracle's spatial pooling against the reference's own lines (:447-462) executed on seeded similarity panels."""
+    g = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    ln, le = torch.from_numpy(g["n4.logits_neg"]), torch.from_numpy(g["n4.logits_evidence"])
+    np.testing.assert_allclose(co.local_pool(ln, None, 40.0, 4.0).numpy(), g["n4.logits_local.plain"], atol=1e-6, rtol=1e-6)
+    np.testing.assert_allclose(co.local_pool(ln, le, 40.0, 4.0).numpy(), g["n4.logits_local.evidence"], atol=1e-9, rtol=1e-5)
