@@ -90,6 +90,15 @@ int leclip_patch_embed_fwd(const void* image, const void* Wp, const float* class
                            int64_t B, int R, int P, int width, leclip_dtype img_dtype, leclip_dtype w_dtype,
                            leclip_dtype x_dtype, void* workspace, void* stream);
 
+/* The same patch embedding with ln_pre fused behind it: X[b, t, :] = ln_pre(embedding row) (clip/model.py:260-265).  The conv
+ * GEMM writes a plain [B*G*G, width] matrix (fast 16-bit epilogue, no residual / row remap); one row-wise pass then does the
+ * class-token concat, the positional add and the LayerNorm.  The positional add happens in fp32 before the LayerNorm (the
+ * un-normalised embedding is never rounded with the positional term in it).  workspace: leclip_patch_embed_ln_workspace_bytes(). */
+int64_t leclip_patch_embed_ln_workspace_bytes(int64_t B, int R, int P, int width, leclip_dtype w_dtype);
+int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, const float* gamma,
+                              const float* beta, void* X, int64_t B, int R, int P, int width, leclip_dtype img_dtype,
+                              leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace, void* stream);
+
 /* Multi-head self-attention core on a packed QKV buffer: out = softmax(q k^T * scale + mask) v per (batch, head).
  * Replaces the scaled-dot-product step inside nn.MultiheadAttention as called at clip/model.py:221-223
  * (mask: clip/model.py:364-370 additive -inf strictly above the diagonal for the text tower).

@@ -73,6 +73,59 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
     }
 }
 
+// Patch-embedding finish fused with ln_pre (clip/model.py:262-265): row (b, t) = LayerNorm(t == 0 ? class_emb : conv_out[b, t-1]) + pos[t])
+// - the class-token concat, the positional add and ln_pre in ONE pass over the residual stream (the GEMM before it then runs
+// the plain 16-bit epilogue instead of the generic one with an fp32 residual and a row remap).  One wave per row.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void embed_ln_pre_kernel(const TI* __restrict__ conv_out, const float* __restrict__ cls,
+                                                           const float* __restrict__ pos, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, TO* __restrict__ y, int64_t rows, int T, int dim,
+                                                           float eps) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int64_t b = row / T;
+    const int t = (int)(row - b * T);
+    const TI* xr = conv_out + (b * (T - 1) + (t > 0 ? t - 1 : 0)) * dim;
+    const float* pr = pos + (int64_t)t * dim;
+    const int nv = dim >> 8, tail = dim & 255;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+            const int c = i * 256 + lane * 4;
+            const f32x4 p4 = *(const f32x4*)(pr + c);
+            const f32x4 a4 = t > 0 ? load4<TI>(xr + c) : *(const f32x4*)(cls + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[i][e] = a4[e] + p4[e];
+            s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float d = v[i][e] - mean; q = fmaf(d, d, q); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    TO* yr = y + row * dim;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        if (i < nv || (i == nv && lane * 4 < tail)) {
+            const int c = i * 256 + lane * 4;
+            const f32x4 g = *(const f32x4*)(gamma + c), bt = *(const f32x4*)(beta + c);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
+            store4<TO>(yr + c, o);
+        }
+    }
+}
+
 template <typename TI>
 int ln_dispatch_out(const void* x, const float* g, const float* b, void* y, int64_t rows, int dim, int64_t ldx,
                     int64_t ldy, float eps, int ydt, hipStream_t s) {
@@ -128,19 +181,41 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const TI* __restrict__ x
 // Merge the per-(row, 64-column block) partials (sum, M2 about the block mean) a GEMM epilogue wrote into (mean, rstd):
 // mean = sum of sums / dim, M2 = sum_b [ M2_b + 64 (mean_b - mean)^2 ]  (Chan et al.'s parallel-variance update, fixed block
 // order): every term is a sum of squares of deviations, so rows whose mean dwarfs their spread lose nothing to cancellation.
-__global__ void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows, int slots,
-                                         int dim, float eps) {
+// One thread per row; all of a row's partials are requested up front as independent 16-byte loads (a run-time trip count made
+// the round-1 kernel a chain of dependent L2 round trips: 7.6 us for 4.8 MB), then merged in the fixed block order.
+template <int SLOTS>
+__global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows,
+                                                                int slots_rt, int dim, float eps) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const f32x2* p = (const f32x2*)(partials + r * slots * 2);
-    float s1 = 0.f;
-    for (int i = 0; i < slots; ++i) s1 += p[i][0];
-    const float mean = s1 / (float)dim;
+    const int slots = SLOTS > 0 ? SLOTS : slots_rt;
     const float bn = (float)(dim / slots);
-    float m2 = 0.f;
-    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
-    stats[2 * r] = mean;
-    stats[2 * r + 1] = rsqrtf(m2 / (float)dim + eps);
+    float s1 = 0.f, m2 = 0.f, mean;
+    if constexpr (SLOTS > 0) {
+        f32x4 v[SLOTS / 2];
+        const f32x4* p = (const f32x4*)(partials + r * SLOTS * 2);
+#pragma unroll
+        for (int i = 0; i < SLOTS / 2; ++i) v[i] = p[i];
+#pragma unroll
+        for (int i = 0; i < SLOTS / 2; ++i) { s1 += v[i][0]; s1 += v[i][2]; }
+        mean = s1 / (float)dim;
+#pragma unroll
+        for (int i = 0; i < SLOTS / 2; ++i) {
+            float dlt = v[i][0] / bn - mean;
+            m2 += fmaf(bn * dlt, dlt, v[i][1]);
+            dlt = v[i][2] / bn - mean;
+            m2 += fmaf(bn * dlt, dlt, v[i][3]);
+        }
+    } else {
+        const f32x2* p = (const f32x2*)(partials + r * slots * 2);
+        for (int i = 0; i < slots; ++i) s1 += p[i][0];
+        mean = s1 / (float)dim;
+        for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
+    }
+    f32x2 o;
+    o[0] = mean;
+    o[1] = rsqrtf(m2 / (float)dim + eps);
+    *(f32x2*)(stats + 2 * r) = o;
 }
 
 // ------------------------------------------------------------------------- gather + LayerNorm + projection
@@ -470,6 +545,50 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
     return leclip_gemm_dispatch(workspace, Wp, B * G * G, width, Kp, Kp, Kp, e, w_dtype, s);
 }
 
+extern "C" int64_t leclip_patch_embed_ln_workspace_bytes(int64_t B, int R, int P, int width, leclip_dtype w_dtype) {
+    const int64_t a = leclip_patch_embed_workspace_bytes(B, R, P, w_dtype);
+    if (a < 0 || width <= 0) return LECLIP_E_INVALID;
+    const int64_t G = R / P;
+    return ((a + 255) & ~(int64_t)255) + B * G * G * width * dtype_size(w_dtype);
+}
+
+extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, const float* gamma,
+                                         const float* beta, void* X, int64_t B, int R, int P, int width, leclip_dtype img_dtype,
+                                         leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace, void* stream) {
+    if (!image || !Wp || !class_emb || !pos || !gamma || !beta || !X || !workspace || B <= 0 || R <= 0 || P <= 0 || R % P || width <= 0) {
+        leclip_set_error("patch_embed_ln: null pointer or inconsistent sizes"); return LECLIP_E_INVALID;
+    }
+    if (!dtype_ok(img_dtype) || !dtype_ok(w_dtype) || !dtype_ok(x_dtype)) { leclip_set_error("patch_embed_ln: bad dtype"); return LECLIP_E_INVALID; }
+    if (width % 64 != 0 || width > 256 * LN_MAXV) { leclip_set_error("patch_embed_ln: width=%d must be a multiple of 64 and <= %d", width, 256 * LN_MAXV); return LECLIP_E_UNSUPPORTED; }
+    hipStream_t s = (hipStream_t)stream;
+    const int G = R / P, T = G * G + 1, Kp = patch_kp(P, w_dtype);
+    const int64_t n_rows = B * G * G;
+    void* conv = (char*)workspace + ((leclip_patch_embed_workspace_bytes(B, R, P, w_dtype) + 255) & ~(int64_t)255);
+    if (P % 8 == 0 && ((uintptr_t)image & 15) == 0) {
+        if (img_dtype == LECLIP_F32) im2col8_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else if (img_dtype == LECLIP_F16) im2col8_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else im2col8_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+    } else {
+        const int64_t total = n_rows * 3 * P;
+        hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp, (int)img_dtype, (int)w_dtype);
+    }
+    int rc = leclip_check_launch("im2col_kernel");
+    if (rc) return rc;
+    EpiParams e;
+    e.bias = nullptr; e.res = nullptr; e.out = conv; e.ldr = 0; e.ldy = width;
+    e.res_dt = LECLIP_F32; e.out_dt = w_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
+    rc = leclip_gemm_dispatch(workspace, Wp, n_rows, width, Kp, Kp, Kp, e, w_dtype, s);
+    if (rc) return rc;
+    const dim3 grid((unsigned)((B * T + 3) / 4)), block(256);
+#define LAUNCH_EMB(TI, TO) hipLaunchKernelGGL((embed_ln_pre_kernel<TI, TO>), grid, block, 0, s, (const TI*)conv, class_emb, pos, gamma, beta, (TO*)X, B * T, T, width, eps)
+    if (w_dtype == LECLIP_F32) { if (x_dtype != LECLIP_F32) { leclip_set_error("patch_embed_ln: fp32 weights need an fp32 stream"); return LECLIP_E_UNSUPPORTED; } LAUNCH_EMB(float, float); }
+    else if (w_dtype == LECLIP_F16) { if (x_dtype == LECLIP_F16) LAUNCH_EMB(f16_t, f16_t); else if (x_dtype == LECLIP_F32) LAUNCH_EMB(f16_t, float); else { leclip_set_error("patch_embed_ln: dtype mix"); return LECLIP_E_UNSUPPORTED; } }
+    else { if (x_dtype == LECLIP_BF16) LAUNCH_EMB(bf16_t, bf16_t); else if (x_dtype == LECLIP_F32) LAUNCH_EMB(bf16_t, float); else { leclip_set_error("patch_embed_ln: dtype mix"); return LECLIP_E_UNSUPPORTED; } }
+#undef LAUNCH_EMB
+    return leclip_check_launch("embed_ln_pre_kernel");
+}
+
 extern "C" int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, int dim, int64_t ldx, float eps, leclip_dtype x_dtype,
                                     void* stream) {
     if (!x || !stats || rows <= 0 || dim <= 0 || ldx < dim || !dtype_ok(x_dtype)) { leclip_set_error("row_stats: bad argument"); return LECLIP_E_INVALID; }
@@ -487,8 +606,13 @@ extern "C" int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, i
 extern "C" int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
                                             void* stream) {
     if (!partials || !stats || rows <= 0 || slots <= 0 || dim <= 0) { leclip_set_error("ln_stats_finalize: bad argument"); return LECLIP_E_INVALID; }
-    hipLaunchKernelGGL(ln_stats_finalize_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partials, stats,
-                       rows, slots, dim, eps);
+    const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = ((uintptr_t)partials & 15) == 0;
+    if (vec && slots == 12) hipLaunchKernelGGL((ln_stats_finalize_kernel<12>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
+    else if (vec && slots == 16) hipLaunchKernelGGL((ln_stats_finalize_kernel<16>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
+    else if (vec && slots == 8) hipLaunchKernelGGL((ln_stats_finalize_kernel<8>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
+    else hipLaunchKernelGGL((ln_stats_finalize_kernel<0>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
     return leclip_check_launch("ln_stats_finalize_kernel");
 }
 

@@ -43,6 +43,9 @@ SIGNATURES = {
     "leclip_patch_embed_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "leclip_patch_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_void_p, c_void_p]),
+    "leclip_patch_embed_ln_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int, c_int]),
+    "leclip_patch_embed_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                          c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "leclip_attention_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int,
                                      c_float, c_int, c_void_p]),
     "leclip_gather_ln_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,

@@ -173,7 +173,8 @@ class VisionEngine:
             self._ws[key] = (
                 _Workspace(rows, self.width, self.dtype, self.device),
                 torch.empty((rows, self.width), dtype=self.dtype, device=self.device),
-                ops.patch_embed_workspace(batch, self.resolution, self.patch, self.dtype, self.device),
+                torch.empty(ops._capi.load().leclip_patch_embed_ln_workspace_bytes(batch, self.resolution, self.patch, self.width,
+                                                                                   ops.dtype_code(self.dtype)), dtype=torch.uint8, device=self.device),
                 (torch.arange(batch, device=self.device, dtype=torch.int64) * self.tokens).contiguous(),
             )
         return self._ws[key]
@@ -184,13 +185,18 @@ class VisionEngine:
         batch = image.shape[0]
         ws, x, patch_ws, cls_rows = self._workspace(batch)
         image = image.contiguous()
-        ops.patch_embed(image, self.wp, self.cls, self.pos, self.patch, self.dtype, workspace=patch_ws,
-                        out=x.view(batch, self.tokens, self.width))
-        if taps is not None:
-            taps["embed"] = x.float().clone()
-        ops.layernorm(x, self.ln_pre_w, self.ln_pre_b, out=x)
-        if taps is not None:
-            taps["ln_pre"] = x.float().clone()
+        if taps is None and self.width % 64 == 0 and self.width <= 4096:
+            # patch GEMM with the plain 16-bit epilogue, then class token + positional add + ln_pre in one row-wise pass
+            ops.patch_embed_ln(image, self.wp, self.cls, self.pos, self.ln_pre_w, self.ln_pre_b, self.patch, self.dtype, workspace=patch_ws,
+                               out=x.view(batch, self.tokens, self.width))
+        else:
+            ops.patch_embed(image, self.wp, self.cls, self.pos, self.patch, self.dtype, workspace=patch_ws,
+                            out=x.view(batch, self.tokens, self.width))
+            if taps is not None:
+                taps["embed"] = x.float().clone()
+            ops.layernorm(x, self.ln_pre_w, self.ln_pre_b, out=x)
+            if taps is not None:
+                taps["ln_pre"] = x.float().clone()
         run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps)
         return x, batch, cls_rows
 

@@ -152,6 +152,33 @@ def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, 
     return out
 
 
+def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor,
+                   beta: torch.Tensor, patch: int, x_dtype: torch.dtype, workspace: Optional[torch.Tensor] = None,
+                   out: Optional[torch.Tensor] = None, eps: float = 1e-5):
+    """ln_pre(patch embedding) in three launches: patch extraction, conv GEMM (plain fast epilogue), fused class-token /
+    positional add / LayerNorm pass (leclip_patch_embed_ln_fwd)."""
+    _dev(image, "image")
+    b, c, r, r2 = image.shape
+    if c != 3 or r != r2 or not image.is_contiguous():
+        raise ValueError("patch_embed_ln: image must be contiguous [B,3,R,R]")
+    width = wp.shape[0]
+    t = (r // patch) ** 2 + 1
+    assert pos.shape == (t, width) and pos.dtype == torch.float32 and class_emb.dtype == torch.float32
+    if workspace is None:
+        nbytes = _capi.load().leclip_patch_embed_ln_workspace_bytes(b, r, patch, width, dtype_code(wp.dtype))
+        workspace = torch.empty(nbytes, dtype=torch.uint8, device=image.device)
+    if out is None:
+        out = torch.empty((b, t, width), dtype=x_dtype, device=image.device)
+    npatch = b * (t - 1)
+    with _Timed("patch_embed", 2 * npatch * width * 3 * patch * patch,
+                image.numel() * image.element_size() + npatch * wp.shape[1] * wp.element_size() * 2 + 3 * b * t * width * out.element_size()):
+        _capi.check(_capi.load().leclip_patch_embed_ln_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(_dev(gamma, "gamma")),
+                                                           _ptr(_dev(beta, "beta")), _ptr(out), b, r, patch, width, dtype_code(image.dtype),
+                                                           dtype_code(wp.dtype), dtype_code(out.dtype), eps, _ptr(workspace), _stream()),
+                    "patch_embed_ln")
+    return out
+
+
 def attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, causal: bool = False,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     rows, width3, ld = _rows2d(qkv, "qkv")

@@ -708,8 +708,12 @@ def test_image_tail_kernel(ops, dt):
         feat_ref = hn.double() @ proj.double()
         ref = co.cosine_logits(feat_ref, txt.double(), 4.0)
         feat, logits = ops.image_tail(x.to(DEV), b, t * d, g.to(DEV), bt.to(DEV), proj.t().contiguous().to(DEV), txt.to(DEV), 4.0, want_features=True)
-        np.testing.assert_allclose(feat.double().cpu().numpy(), feat_ref.numpy(), atol=2e-5 * float(feat_ref.abs().max()) + 1e-5, rtol=0)
-        np.testing.assert_allclose(logits.double().cpu().numpy(), ref.numpy(), atol=5e-6, rtol=0)
+        # 16-bit modes: the kernel's fp32 LayerNorm and the oracle's can round an element of h to neighbouring 16-bit values
+        ftol = _tol(dt, 2e-5, 1e-3, 8e-3)
+        np.testing.assert_allclose(feat.double().cpu().numpy(), feat_ref.numpy(), atol=ftol * float(feat_ref.abs().max()) + 1e-5, rtol=0)
+        np.testing.assert_allclose(logits.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 5e-6, 2e-3, 1.6e-2), rtol=0)
+        # the logit contraction itself is exact fp32 on the kernel's own features
+        np.testing.assert_allclose(logits.double().cpu().numpy(), co.cosine_logits(feat.double().cpu(), txt.double(), 4.0).numpy(), atol=5e-6, rtol=0)
         f_only, none = ops.image_tail(x.to(DEV), b, t * d, g.to(DEV), bt.to(DEV), proj.t().contiguous().to(DEV))
         assert none is None and torch.equal(f_only, feat)
         none, l_only = ops.image_tail(x.to(DEV), b, t * d, g.to(DEV), bt.to(DEV), proj.t().contiguous().to(DEV), txt.to(DEV), 4.0)
