@@ -44,24 +44,49 @@ struct TailArgs {
 
 constexpr int TAIL_MAXV = 4;   // d <= 1024
 
-// proj GEMM for one wave: columns [n_lo, n_hi) in tiles of 16, A = LayerNorm output in LDS
+// proj GEMM for one wave: column tiles wave, wave + 4, ... (16 columns each, at most PT_MAX per wave), A = LayerNorm output in
+// LDS.  K is the OUTER loop: the B fragments of all of the wave's tiles for a k-step are independent 16-byte loads straight
+// from L2 (proj^T is 0.8 MB, shared by every workgroup), requested one k-step ahead of the MFMAs that consume them.
+constexpr int PT_MAX = 12;   // E <= 768 per 4 waves
 template <typename T>
 __device__ __forceinline__ void proj_tiles(const TailArgs& a, const char* sh, int hpitch, float* sfeat, int fpitch, int wave, int lane) {
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, fc = lane >> 4;
-    const T* P = (const T*)a.proj_t;
-    for (int nt = wave; nt * 16 < a.E; nt += 4) {
-        acc4 acc = {0.f, 0.f, 0.f, 0.f};
-        const T* prow = P + (int64_t)(nt * 16 + fr) * a.d + fc * 8;
-        const char* hrow = sh + fr * hpitch + fc * 16;
-        for (int k = 0; k < a.d; k += 32) {
-            const v8 af = *(const v8*)(hrow + k * 2);
-            const v8 bf = *(const v8*)(prow + k);
-            acc = mfma16(af, bf, acc);
-        }
+    const int ntiles = a.E >> 4;
+    const int mine = (ntiles - wave + 3) >> 2;            // tiles of this wave
+    const T* prow = (const T*)a.proj_t + (int64_t)(wave * 16 + fr) * a.d + fc * 8;
+    const int64_t tstride = (int64_t)64 * a.d;            // wave's next tile: 4 tiles = 64 proj^T rows further
+    const char* hrow = sh + fr * hpitch + fc * 16;
+    acc4 acc[PT_MAX];
+    v8 bq[2][PT_MAX];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) sfeat[(4 * fc + r) * fpitch + nt * 16 + fr] = acc[r];
+    for (int i = 0; i < PT_MAX; ++i) acc[i] = acc4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[0][i] = *(const v8*)(prow + i * tstride);
+    for (int k = 0; k < a.d; k += 64) {                   // d % 64 == 0: two k-steps per iteration, static buffer indices
+#pragma unroll
+        for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[1][i] = *(const v8*)(prow + i * tstride + k + 32);
+        {
+            const v8 af = *(const v8*)(hrow + k * 2);
+#pragma unroll
+            for (int i = 0; i < PT_MAX; ++i) if (i < mine) acc[i] = mfma16(af, bq[0][i], acc[i]);
+        }
+        if (k + 64 < a.d) {
+#pragma unroll
+            for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[0][i] = *(const v8*)(prow + i * tstride + k + 64);
+        }
+        {
+            const v8 af = *(const v8*)(hrow + (k + 32) * 2);
+#pragma unroll
+            for (int i = 0; i < PT_MAX; ++i) if (i < mine) acc[i] = mfma16(af, bq[1][i], acc[i]);
+        }
     }
+#pragma unroll
+    for (int i = 0; i < PT_MAX; ++i)
+        if (i < mine) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sfeat[(4 * fc + r) * fpitch + (wave + 4 * i) * 16 + fr] = acc[i][r];
+        }
 }
 template <>
 __device__ __forceinline__ void proj_tiles<float>(const TailArgs& a, const char* sh, int hpitch, float* sfeat, int fpitch, int wave, int lane) {
@@ -73,6 +98,7 @@ __device__ __forceinline__ void proj_tiles<float>(const TailArgs& a, const char*
         acc4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* prow = P + (int64_t)(nt * 16 + fr) * a.d + 4 * fq;
         const char* hrow = sh + fr * hpitch + 16 * fq;
+#pragma unroll 4
         for (int k = 0; k < a.d; k += 16) {
             const f32x4 af = *(const f32x4*)(hrow + k * 4);
             const f32x4 bf = *(const f32x4*)(prow + k);
@@ -129,14 +155,19 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
                 tstore4<T>((T*)(sh + row * hpitch) + c, o);
             }
     }
-    // |t_c|^2 of the text features (every workgroup needs all C of them: 0.16 MB from L2)
+    // |t_c|^2 of the text features (every workgroup needs all C of them: 0.16 MB from L2); four rows per wave in flight
     if (a.txt) {
-        for (int c = wave; c < a.C; c += 4) {
-            const float* tr = a.txt + (int64_t)c * a.E;
-            float s = 0.f;
-            for (int k = lane * 4; k < a.E; k += 256) { const f32x4 t = *(const f32x4*)(tr + k); s = fmaf(t[0], t[0], s); s = fmaf(t[1], t[1], s); s = fmaf(t[2], t[2], s); s = fmaf(t[3], t[3], s); }
-            s = wave_sum(s);
-            if (lane == 0) stnorm[c] = s;
+        for (int c0 = wave * 4; c0 < a.C; c0 += 16) {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int k = lane * 4; k < a.E; k += 256) {
+                f32x4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int c = c0 + u < a.C ? c0 + u : a.C - 1; t[u] = *(const f32x4*)(a.txt + (int64_t)c * a.E + k); }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { s4[u] = fmaf(t[u][0], t[u][0], s4[u]); s4[u] = fmaf(t[u][1], t[u][1], s4[u]); s4[u] = fmaf(t[u][2], t[u][2], s4[u]); s4[u] = fmaf(t[u][3], t[u][3], s4[u]); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const float r = wave_sum(s4[u]); if (lane == 0 && c0 + u < a.C) stnorm[c0 + u] = r; }
         }
     }
     __syncthreads();
@@ -167,6 +198,7 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
         const float* trow = a.txt + (int64_t)cc * a.E + 4 * fq;
         const float* frow = sfeat + fr * fpitch + 4 * fq;
         acc4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
         for (int k = 0; k < a.E; k += 16) {
             const f32x4 af = *(const f32x4*)(frow + k);
             const f32x4 bf = *(const f32x4*)(trow + k);
@@ -322,8 +354,8 @@ extern "C" int leclip_image_tail_fwd(const void* x, const float* gamma, const fl
     }
     if (!dtype_ok(dtype)) { leclip_set_error("image_tail: bad dtype"); return LECLIP_E_INVALID; }
     const int kq = dtype == LECLIP_F32 ? 16 : 32;
-    if (dim % 64 != 0 || dim > 256 * TAIL_MAXV || dim % kq != 0 || E % 16 != 0 || E > 2048 || C > 4096) {
-        leclip_set_error("image_tail: dim=%d must be a multiple of 64 and <= %d, E=%d a multiple of 16 (<= 2048), C=%d <= 4096", dim, 256 * TAIL_MAXV, E, C);
+    if (dim % 64 != 0 || dim > 256 * TAIL_MAXV || dim % kq != 0 || E % 16 != 0 || E > 64 * PT_MAX || C > 4096) {
+        leclip_set_error("image_tail: dim=%d must be a multiple of 64 and <= %d, E=%d a multiple of 16 (<= %d), C=%d <= 4096", dim, 256 * TAIL_MAXV, E, 64 * PT_MAX, C);
         return LECLIP_E_UNSUPPORTED;
     }
     const int esz = dtype_size(dtype);

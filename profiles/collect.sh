@@ -1,0 +1,31 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (via gpurun):  bash profiles/collect.sh r02
+# kernel-trace stats + separate PMC passes (never combined with other trace domains) for the benchmark command, the
+# ViT-L/14@336 large-model point (BASELINE configs[4], one GPU's share B=128) and the prompt-tuning step (configs[2]).
+# Raw output under gpurun_out/prof_<tag>/ ; `python profiles/summarize.py <tag>` turns it into the committed files.
+set -o pipefail
+TAG=${1:-r02}
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-second-dtype"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || exit 1
+echo trace done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || exit 1
+echo pmc mem done
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1 || exit 1
+echo pmc sq done
+VITL="python3 $R/bench.py --arch ViT-L/14@336px --batch 128 --steps 3 --warmup 1 --no-cpu-baseline --no-second-dtype"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vitl -- $VITL > $OUT/vitl.log 2>&1 || exit 1
+echo vitl done
+TUNE="python3 $R/bench.py --mode tune --dtype bf16 --steps 4 --warmup 2"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tune -- $TUNE > $OUT/tune.log 2>&1 || exit 1
+cd $R
+timeout -k 10 300 python3 bench.py --arch ViT-L/14@336px --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --no-second-dtype > $OUT/vitl_bench.json 2> $OUT/vitl_bench.err || exit 1
+timeout -k 10 300 python3 bench.py --mode tune --dtype bf16 --steps 10 --warmup 3 > $OUT/tune_bench.json 2> $OUT/tune_bench.err || exit 1
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo collected
