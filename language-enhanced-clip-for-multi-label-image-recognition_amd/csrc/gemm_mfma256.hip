@@ -110,6 +110,16 @@ struct PP {
     char* smem;
     acc4 acc[2][4][4];
     v8 af[4], bfr[4];
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+    unsigned* fine;      // diagnostic build: LDS slot array of this wave for the per-phase timeline of ONE K-tile (null = off)
+    int fine_i;
+#define FSTAMP()                                                                                                   \
+    do {                                                                                                           \
+        if (fine) { if ((threadIdx.x & 63) == 0) fine[fine_i] = (unsigned)__builtin_amdgcn_s_memtime(); ++fine_i; } \
+    } while (0)
+#else
+#define FSTAMP() do { } while (0)
+#endif
 
     __device__ __forceinline__ void stage_a(int stage, int kh, int k_elem) {
         char* slot = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES;
@@ -134,8 +144,11 @@ struct PP {
         for (int j = 0; j < 4; ++j) bfr[j] = *(const v8*)(p + j * 1024);
     }
     __device__ __forceinline__ void compute(int rh) {
+        FSTAMP();                                   // memory cluster issued
         __builtin_amdgcn_s_barrier();
+        FSTAMP();                                   // past the first barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        FSTAMP();                                   // fragments in registers
         PIN();
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -144,7 +157,9 @@ struct PP {
             for (int j = 0; j < 4; ++j) acc[rh][i][j] = SWAP ? mfma16(bfr[j], af[i], acc[rh][i][j]) : mfma16(af[i], bfr[j], acc[rh][i][j]);
         __builtin_amdgcn_s_setprio(0);
         PIN();
+        FSTAMP();                                   // 16 MFMAs issued
         __builtin_amdgcn_s_barrier();
+        FSTAMP();                                   // past the second barrier
         PIN();
     }
 
@@ -278,6 +293,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     constexpr bool T16 = CFG >= 0 && PF != 1;
     PP<T, T16> p;
     p.smem = smem;
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+    p.fine = nullptr;
+    p.fine_i = 0;
+#endif
     // fragment reads (v_mfma_f32_16x16x32 operand map): lane l -> row l&15 of a 16-row tile, 16-byte chunk l>>4
     {
         const int fr = lane & 15, fc = lane >> 4;
@@ -376,7 +395,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         auto next_src = [&] { set_sources(m0n, n0n); };
         int t = 0;
         if (DIAG(g.dbg) & 4) t = nk - 2 > 0 ? nk - 2 : 0;
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+        for (; t + 2 < nk; ++t) {
+            // per-phase timeline of K-tiles 4 and 5 of the workgroup's first tile, waves 0 and 4 (the two waves of SIMD 0)
+            const bool on = g.stamps && tile_it == 0 && (t == 4 || t == 5) && (wave == 0 || wave == 4);
+            p.fine = on ? (unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 64 + (t - 4) * 20 : nullptr;
+            p.fine_i = 0;
+            p.template ktile<0, EPI_STORES>(t, false, next_src);
+        }
+        p.fine = nullptr;
+#else
         for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
+#endif
         p.template ktile<1, EPI_STORES>(t, nx, next_src);
 
         // T16 flavour: the per-column constants (bias | fused-LayerNorm column sums: 2 x 256 floats per tile, one per
@@ -399,6 +429,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         }
         p.template ktile<2>(t + 1, nx, next_src);
         STAMP(1);
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+        if (g.stamps && tile_it == 0 && (wave == 0 || wave == 4) && lane < 40) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const unsigned* f = (const unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 64;
+            ((unsigned*)(g.stamps + 256 * 16 * 8))[(blockIdx.x * 2 + (wave >> 2)) * 40 + lane] = f[lane];
+        }
+#endif
 
         // Epilogue operands (bias, LayerNorm column sums, and - for the whole tile, 16 chunks per lane - the 16-bit
         // residual or the fused LayerNorm's (mean, rstd)) are requested right after the last MFMA

@@ -186,7 +186,8 @@ static void stamps() {
         {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
     const int dt = LECLIP_BF16;
     const size_t n_st = 256 * 16 * 8;
-    Buf dS(n_st * 8);
+    const size_t n_fine = 256 * 2 * 40;                 // per workgroup, waves 0 / 4: 2 K-tiles x 4 phases x 5 stamps (32-bit)
+    Buf dS(n_st * 8 + n_fine * 4);
     for (auto& s : shapes) {
         auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
         auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
@@ -198,13 +199,13 @@ static void stamps() {
         };
         leclip_gemm256_set_stamps(nullptr);
         for (int i = 0; i < 200; ++i) run();   // settle the clock
-        HIPCHK(hipMemset(dS.d, 0, n_st * 8));
+        HIPCHK(hipMemset(dS.d, 0, n_st * 8 + n_fine * 4));
         leclip_gemm256_set_stamps((unsigned long long*)dS.d);
         run();
         HIPCHK(hipDeviceSynchronize());
         leclip_gemm256_set_stamps(nullptr);
         std::vector<unsigned long long> st(n_st);
-        dS.down(st.data());
+        HIPCHK(hipMemcpy(st.data(), dS.d, n_st * 8, hipMemcpyDeviceToHost));
         // per tile index: mean over workgroups of the five segment lengths (cycles)
         printf("stamps %-10s N=%d K=%d   (cycles, mean over workgroups; wave 0)\n", s.name, s.N, s.K);
         printf("  tile   n_wg   kloop  close+operands  prologue-issue  passes  wait-at-next-top   tile-total\n");
@@ -224,6 +225,32 @@ static void stamps() {
             if (!n) break;
             printf("  %4d  %5d  %6.0f  %14.0f  %14.0f  %6.0f  %16.0f  %11.0f\n", it, n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n,
                    n_next ? seg[4] / n_next : 0.0, n_next ? seg[5] / n_next : 0.0);
+        }
+        {   // per-phase timeline of K-tiles 4-5 (first tile), mean over workgroups, waves 0 and 4 (partners on one SIMD):
+            // segments: mem-cluster-issued -> [wait at barrier 1] -> [lgkmcnt] -> [16 MFMAs issue] -> [wait at barrier 2] -> next phase's memory cluster
+            std::vector<unsigned> fs(n_fine);
+            HIPCHK(hipMemcpy(fs.data(), (char*)dS.d + n_st * 8, n_fine * 4, hipMemcpyDeviceToHost));
+            for (int wv = 0; wv < 2; ++wv) {
+                double seg[8][5] = {};
+                int n = 0;
+                for (int wg = 0; wg < 256; ++wg) {
+                    const unsigned* f = &fs[(size_t)(wg * 2 + wv) * 40];
+                    if (!f[0] || !f[39]) continue;
+                    ++n;
+                    for (int ph = 0; ph < 8; ++ph) {
+                        const unsigned* q = f + ph * 5;
+                        seg[ph][0] += (double)(unsigned)(q[1] - q[0]);      // barrier 1 wait
+                        seg[ph][1] += (double)(unsigned)(q[2] - q[1]);      // lgkmcnt(0)
+                        seg[ph][2] += (double)(unsigned)(q[3] - q[2]);      // MFMA cluster issue
+                        seg[ph][3] += (double)(unsigned)(q[4] - q[3]);      // barrier 2 wait
+                        if (ph < 7) seg[ph][4] += (double)(unsigned)(q[5] - q[4]);   // next memory cluster (reads + DMA issue + vmcnt)
+                    }
+                }
+                if (!n) continue;
+                printf("  fine wave %d (n=%d): phase  bar1  lgkm  mfma16  bar2  memcluster(next)\n", wv * 4, n);
+                for (int ph = 0; ph < 8; ++ph)
+                    printf("    kt%d.p%d  %5.0f %5.0f %6.0f %5.0f %6.0f\n", 4 + ph / 4, ph % 4, seg[ph][0] / n, seg[ph][1] / n, seg[ph][2] / n, seg[ph][3] / n, seg[ph][4] / n);
+            }
         }
         // skew between workgroups at the first and the last stamp
         unsigned long long lo0 = ~0ull, hi0 = 0, lo4 = ~0ull, hi4 = 0;
