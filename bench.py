@@ -249,7 +249,9 @@ def tune(args):
     cfg = get_cfg_default()
     cfg.merge_from_list(["MODEL.BACKBONE.NAME", args.arch, "MODEL.BACKBONE.PATH", "synthetic:0:cond", "TRAINER.Caption.PREC",
                          args.dtype, "TRAIN.LOSSFUNC", "bce", "OPTIM.WARMUP_EPOCH", "0"])
-    tr = build_trainer(cfg)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):     # the trainer announces itself on stdout like the reference; stdout carries ONE JSON line
+        tr = build_trainer(cfg)
     arch = synth.ARCHS[args.arch]
     images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(tr.device)
     labels = torch.from_numpy((synth.uniform(3 + rank, "tune.labels", (B, 80), 0, 1) < 0.04).astype("float32")).to(tr.device)

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 3
+#define LECLIP_ABI_VERSION 4
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -74,6 +74,17 @@ int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, co
                              const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M, int N,
                              int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
                              leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream);
+/* The same fused-LayerNorm GEMM fed with the PRODUCER's block partials instead of finished statistics: ln_partials
+ * [M][ln_slots][2] (ln_slots = K / 64) as written by a stats_out epilogue or by leclip_patch_embed_ln_fwd.  The function
+ * merges them (leclip_ln_stats_finalize_fwd's kernel) into ln_stats_ws [M][2] and runs the GEMM: one C call per consumer.
+ * (Merging inside the 256x256 GEMM kernel was built and measured in round 2 and costs more than the launch it saves: the
+ * specialised LayerNorm-epilogue kernels have no registers left for a row's partials - DESIGN.md section 6.)
+ * Give ln_stats OR ln_partials. */
+int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const float* bias, const float* ln_stats, const float* ln_partials,
+                                int ln_slots, float* ln_stats_ws, float ln_eps, const float* ln_colsum, const void* residual,
+                                void* Y, float* stats_out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr,
+                                int64_t ldy, leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
+                                leclip_dtype y_dtype, void* stream);
 /* (mean, rstd) per row: from the partial sums above (fixed summation order), or directly from rows of x. */
 int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
                                  void* stream);
@@ -96,8 +107,12 @@ int leclip_patch_embed_fwd(const void* image, const void* Wp, const float* class
  * un-normalised embedding is never rounded with the positional term in it).  workspace: leclip_patch_embed_ln_workspace_bytes(). */
 int64_t leclip_patch_embed_ln_workspace_bytes(int64_t B, int R, int P, int width, leclip_dtype w_dtype);
 int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, const float* gamma,
-                              const float* beta, void* X, int64_t B, int R, int P, int width, leclip_dtype img_dtype,
-                              leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace, void* stream);
+                              const float* beta, void* X, float* stats_out, int64_t B, int R, int P, int width,
+                              leclip_dtype img_dtype, leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace,
+                              void* stream);
+/* stats_out (nullable) [B*T][width/64][2]: (sum, M2 about the block mean) of the stored rows per 64-column block - the block
+ * partials the first residual block's fused LayerNorm merges in place (leclip_gemm_ln_partials_fwd), so that no separate
+ * row-statistics pass runs over the fresh residual stream. */
 
 /* Multi-head self-attention core on a packed QKV buffer: out = softmax(q k^T * scale + mask) v per (batch, head).
  * Replaces the scaled-dot-product step inside nn.MultiheadAttention as called at clip/model.py:221-223

@@ -225,6 +225,11 @@ int launch_mfma(const GemmArgs& a, hipStream_t s) {
 
 int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                            const EpiParams& epi, hipStream_t s);
+extern "C" int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const float* bias, const float* ln_stats, const float* ln_partials,
+                                           int ln_slots, float* ln_stats_ws, float ln_eps, const float* ln_colsum, const void* residual,
+                                           void* Y, float* stats_out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr,
+                                           int64_t ldy, leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
+                                           leclip_dtype y_dtype, void* stream);
 bool leclip_gemm256_eligible(int64_t M, int N, int K);
 int leclip_gemm256_cus();
 int launch_128(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi,
@@ -292,14 +297,25 @@ extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const 
     EpiParams e;
     e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
     e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
     return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
 }
+
+int leclip_ln_stats_finalize_launch(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps, hipStream_t s);
 
 extern "C" int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
                                         const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M,
                                         int N, int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
                                         leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream) {
+    return leclip_gemm_ln_partials_fwd(A, W, bias, ln_stats, nullptr, 0, nullptr, 0.f, ln_colsum, residual, Y, stats_out, M, N, K, lda, ldw,
+                                       ldr, ldy, act, ab_dtype, res_dtype, y_dtype, stream);
+}
+
+extern "C" int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const float* bias, const float* ln_stats, const float* ln_partials,
+                                           int ln_slots, float* ln_stats_ws, float ln_eps, const float* ln_colsum, const void* residual,
+                                           void* Y, float* stats_out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr,
+                                           int64_t ldy, leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
+                                           leclip_dtype y_dtype, void* stream) {
     if (!A || !W || !Y || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldy < N || (residual && ldr < N)) {
         leclip_set_error("gemm_ln_fused: null pointer or inconsistent sizes (M=%lld N=%d K=%d)", (long long)M, N, K);
         return LECLIP_E_INVALID;
@@ -309,14 +325,28 @@ extern "C" int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const floa
         leclip_set_error("gemm_ln_fused: 16-bit operands only (the fp32 parity path keeps LayerNorm as its own kernel)");
         return LECLIP_E_UNSUPPORTED;
     }
-    if ((ln_stats != nullptr) != (ln_colsum != nullptr) || (ln_stats && !bias) || (ln_colsum && ((uintptr_t)ln_colsum & 15)) ||
-        (stats_out && ((uintptr_t)stats_out & 7))) {
-        leclip_set_error("gemm_ln_fused: ln_stats, ln_colsum and bias go together; ln_colsum 16-byte, stats_out 8-byte aligned");
+    if (ln_stats && ln_partials) { leclip_set_error("gemm_ln_fused: give ln_stats OR ln_partials, not both"); return LECLIP_E_INVALID; }
+    const bool ln = ln_stats != nullptr || ln_partials != nullptr;
+    if (ln != (ln_colsum != nullptr) || (ln && !bias) || (ln_colsum && ((uintptr_t)ln_colsum & 15)) || (stats_out && ((uintptr_t)stats_out & 7)) ||
+        (ln_partials && (ln_slots <= 0 || K % ln_slots != 0 || ((uintptr_t)ln_partials & 7)))) {
+        leclip_set_error("gemm_ln_fused: LayerNorm statistics, ln_colsum and bias go together; ln_colsum 16-byte, stats_out / ln_partials 8-byte aligned");
         return LECLIP_E_INVALID;
     }
+    hipStream_t s = (hipStream_t)stream;
     EpiParams e;
     e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
     e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
     e.ln_stats = ln_stats; e.ln_colsum = ln_colsum; e.stats_out = stats_out; e.stats_slots = N / 64;
-    return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
+    e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = ln_eps;
+    if (ln_partials) {
+        // The merge (Chan's parallel-variance update, ln_merge_partials) runs as its own small launch into ln_stats_ws.  Merging
+        // inside the consuming 256x256 kernel was built and measured in round 2: the row's 12 partial pairs have to be held in
+        // registers across the last K-tile, the specialised LayerNorm epilogue kernels sit at 251 of 256 VGPRs, the spill cost
+        // 11 % end to end (profiles/r02_ab_ln_merge_in_kernel.txt) against the 1.5 % the 23 launches cost.
+        if (!ln_stats_ws) { leclip_set_error("gemm_ln_fused: ln_partials needs the [M, 2] statistics workspace (ln_stats_ws)"); return LECLIP_E_INVALID; }
+        const int rc = leclip_ln_stats_finalize_launch(ln_partials, ln_stats_ws, M, ln_slots, K, ln_eps, s);
+        if (rc) return rc;
+        e.ln_stats = ln_stats_ws;
+    }
+    return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, s);
 }

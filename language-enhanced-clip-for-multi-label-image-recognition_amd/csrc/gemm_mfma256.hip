@@ -750,12 +750,13 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
     const EpiParams& e = a.epi;
     const int tdt = sizeof(T) == 2 && __is_same(T, bf16_t) ? LECLIP_BF16 : LECLIP_F16;
     // specialised epilogues: output (and residual) in the operand dtype, no row remap, one of the six hot combinations
-    const bool fast_ok = !force_generic && e.out_dt == tdt && !e.rowmap_P && (!e.res || e.res_dt == tdt) && !(e.res && e.ln_stats);
+    const bool ln = e.ln_stats != nullptr;
+    const bool fast_ok = !force_generic && e.out_dt == tdt && !e.rowmap_P && (!e.res || e.res_dt == tdt) && !(e.res && ln);
     if (fast_ok) {
         const bool gelu = e.act == LECLIP_ACT_QUICKGELU, stats = e.stats_out != nullptr;
-        if (!e.res && !e.ln_stats && !stats) return gelu ? launch256_pf<T, 0, 1>(a, grid, s) : launch256_pf<T, 0, 0>(a, grid, s);
+        if (!e.res && !ln && !stats) return gelu ? launch256_pf<T, 0, 1>(a, grid, s) : launch256_pf<T, 0, 0>(a, grid, s);
         if (e.res && !gelu) return stats ? launch256_pf<T, 1, 2>(a, grid, s) : launch256_pf<T, 1, 0>(a, grid, s);
-        if (e.ln_stats && !stats) return gelu ? launch256_pf<T, 2, 1>(a, grid, s) : launch256_pf<T, 2, 0>(a, grid, s);
+        if (ln && !stats) return gelu ? launch256_pf<T, 2, 1>(a, grid, s) : launch256_pf<T, 2, 0>(a, grid, s);
     }
     return launch256_pf<T, 3, -1>(a, grid, s);   // everything else (fp32 output or residual, row remap, rare combinations)
 }

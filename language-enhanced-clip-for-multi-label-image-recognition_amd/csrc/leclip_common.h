@@ -100,6 +100,9 @@ struct EpiParams {
     //   v = rstd[m] * (acc - mean[m] * ln_colsum[n]) + bias[n]      with bias[n] = sum_k beta[k] W[n,k] + b[n]
     const float* ln_stats;   // [M][2] = (mean, rstd) per row, or null
     const float* ln_colsum;  // [N]    = sum_k (gamma[k] W[n,k])
+    const float* ln_partials;   // (reserved: block partials are merged by the finalize kernel before dispatch, see gemm_mfma.hip)
+    int ln_slots;
+    float ln_eps;
     // Row statistics of the OUTPUT for the next LayerNorm: (sum, sum of squared deviations from the block mean) of the
     // rounded outputs per (row, 64-column block), written - not accumulated - so the result is deterministic and needs no
     // zeroing; leclip_ln_stats_finalize_fwd merges the blocks (parallel-variance update, no E[x^2] - mean^2 cancellation).
@@ -108,6 +111,32 @@ struct EpiParams {
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+// Merge a row's block partials (sum, M2 about the block mean; two blocks per f32x4) into (mean, rstd): Chan et al.'s
+// parallel-variance update in a fixed block order.  ONE definition for the finalize kernel and for the GEMM kernels that
+// merge in place, so that both produce the same bits (batch invariance across kernel families).
+constexpr int LN_MERGE_MAXV = 8;   // <= 16 blocks of 64 columns: dim <= 1024
+__device__ __forceinline__ f32x2 ln_merge_partials(const f32x4 (&v)[LN_MERGE_MAXV], int slots, int dim, float eps) {
+    float s1 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MERGE_MAXV; ++i)
+        if (2 * i < slots) { s1 += v[i][0]; s1 += v[i][2]; }
+    const float mean = s1 / (float)dim;
+    const float bn = (float)(dim / slots);
+    float m2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MERGE_MAXV; ++i)
+        if (2 * i < slots) {
+            float dlt = v[i][0] / bn - mean;
+            m2 += fmaf(bn * dlt, dlt, v[i][1]);
+            dlt = v[i][2] / bn - mean;
+            m2 += fmaf(bn * dlt, dlt, v[i][3]);
+        }
+    f32x2 o;
+    o[0] = mean;
+    o[1] = rsqrtf(m2 / (float)dim + eps);
+    return o;
+}
 
 // Shared 8-wide epilogue step of the 16-bit GEMM kernels: lane holds columns n..n+7 of output row m (8 lanes per
 // row: lanes with equal lane>>3).  b8 = bias chunk, s8 = ln_colsum chunk.

@@ -79,8 +79,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const TI* __restrict__ x
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const TI* __restrict__ conv_out, const float* __restrict__ cls,
                                                            const float* __restrict__ pos, const float* __restrict__ gamma,
-                                                           const float* __restrict__ beta, TO* __restrict__ y, int64_t rows, int T, int dim,
-                                                           float eps) {
+                                                           const float* __restrict__ beta, TO* __restrict__ y, float* __restrict__ stats_out,
+                                                           int64_t rows, int T, int dim, float eps) {
     const int lane = threadIdx.x & 63;
     const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -122,6 +122,27 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const TI* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + bt[e];
             store4<TO>(yr + c, o);
+            if (stats_out) {
+                // (sum, M2 about the block mean) of the STORED values per 64-column block (16 lanes x 4), the same quantities a
+                // GEMM epilogue emits: the first block's fused LayerNorm merges them in place (no row-statistics pass)
+                float r4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r4[e] = (float)(TO)o[e];
+                float s1 = (r4[0] + r4[1]) + (r4[2] + r4[3]);
+#pragma unroll
+                for (int of = 1; of < 16; of <<= 1) s1 += __shfl_xor(s1, of);
+                const float mb = s1 * (1.0f / 64.0f);
+                float m2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float dl = r4[e] - mb; m2 = fmaf(dl, dl, m2); }
+#pragma unroll
+                for (int of = 1; of < 16; of <<= 1) m2 += __shfl_xor(m2, of);
+                if ((lane & 15) == 0) {
+                    f32x2 w;
+                    w[0] = s1; w[1] = m2;
+                    *(f32x2*)(stats_out + (row * (dim >> 6) + (i * 4 + (lane >> 4))) * 2) = w;
+                }
+            }
         }
     }
 }
@@ -181,41 +202,34 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const TI* __restrict__ x
 // Merge the per-(row, 64-column block) partials (sum, M2 about the block mean) a GEMM epilogue wrote into (mean, rstd):
 // mean = sum of sums / dim, M2 = sum_b [ M2_b + 64 (mean_b - mean)^2 ]  (Chan et al.'s parallel-variance update, fixed block
 // order): every term is a sum of squares of deviations, so rows whose mean dwarfs their spread lose nothing to cancellation.
-// One thread per row; all of a row's partials are requested up front as independent 16-byte loads (a run-time trip count made
-// the round-1 kernel a chain of dependent L2 round trips: 7.6 us for 4.8 MB), then merged in the fixed block order.
-template <int SLOTS>
+// One thread per row; all of a row's partials are requested up front as independent 16-byte loads, then merged in the fixed
+// block order by ln_merge_partials (shared with the GEMM kernels that merge in place).
 __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows,
-                                                                int slots_rt, int dim, float eps) {
+                                                                int slots, int dim, float eps) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const int slots = SLOTS > 0 ? SLOTS : slots_rt;
+    f32x4 v[LN_MERGE_MAXV];
+    const f32x4* p = (const f32x4*)(partials + r * slots * 2);
+#pragma unroll
+    for (int i = 0; i < LN_MERGE_MAXV; ++i)
+        if (2 * i < slots) v[i] = p[i];
+    *(f32x2*)(stats + 2 * r) = ln_merge_partials(v, slots, dim, eps);
+}
+
+// any slot count (odd, > 16): plain loop, same formula
+__global__ void ln_stats_finalize_generic_kernel(const float* __restrict__ partials, float* __restrict__ stats, int64_t rows, int slots,
+                                                 int dim, float eps) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= rows) return;
+    const f32x2* p = (const f32x2*)(partials + r * slots * 2);
+    float s1 = 0.f;
+    for (int i = 0; i < slots; ++i) s1 += p[i][0];
+    const float mean = s1 / (float)dim;
     const float bn = (float)(dim / slots);
-    float s1 = 0.f, m2 = 0.f, mean;
-    if constexpr (SLOTS > 0) {
-        f32x4 v[SLOTS / 2];
-        const f32x4* p = (const f32x4*)(partials + r * SLOTS * 2);
-#pragma unroll
-        for (int i = 0; i < SLOTS / 2; ++i) v[i] = p[i];
-#pragma unroll
-        for (int i = 0; i < SLOTS / 2; ++i) { s1 += v[i][0]; s1 += v[i][2]; }
-        mean = s1 / (float)dim;
-#pragma unroll
-        for (int i = 0; i < SLOTS / 2; ++i) {
-            float dlt = v[i][0] / bn - mean;
-            m2 += fmaf(bn * dlt, dlt, v[i][1]);
-            dlt = v[i][2] / bn - mean;
-            m2 += fmaf(bn * dlt, dlt, v[i][3]);
-        }
-    } else {
-        const f32x2* p = (const f32x2*)(partials + r * slots * 2);
-        for (int i = 0; i < slots; ++i) s1 += p[i][0];
-        mean = s1 / (float)dim;
-        for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
-    }
-    f32x2 o;
-    o[0] = mean;
-    o[1] = rsqrtf(m2 / (float)dim + eps);
-    *(f32x2*)(stats + 2 * r) = o;
+    float m2 = 0.f;
+    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
+    stats[2 * r] = mean;
+    stats[2 * r + 1] = rsqrtf(m2 / (float)dim + eps);
 }
 
 // ------------------------------------------------------------------------- gather + LayerNorm + projection
@@ -541,7 +555,7 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
     EpiParams e;
     e.bias = nullptr; e.res = pos; e.out = X; e.ldr = width; e.ldy = width;
     e.res_dt = LECLIP_F32; e.out_dt = x_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = G * G;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
     return leclip_gemm_dispatch(workspace, Wp, B * G * G, width, Kp, Kp, Kp, e, w_dtype, s);
 }
 
@@ -553,8 +567,9 @@ extern "C" int64_t leclip_patch_embed_ln_workspace_bytes(int64_t B, int R, int P
 }
 
 extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* class_emb, const float* pos, const float* gamma,
-                                         const float* beta, void* X, int64_t B, int R, int P, int width, leclip_dtype img_dtype,
-                                         leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace, void* stream) {
+                                         const float* beta, void* X, float* stats_out, int64_t B, int R, int P, int width,
+                                         leclip_dtype img_dtype, leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace,
+                                         void* stream) {
     if (!image || !Wp || !class_emb || !pos || !gamma || !beta || !X || !workspace || B <= 0 || R <= 0 || P <= 0 || R % P || width <= 0) {
         leclip_set_error("patch_embed_ln: null pointer or inconsistent sizes"); return LECLIP_E_INVALID;
     }
@@ -577,11 +592,11 @@ extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, cons
     EpiParams e;
     e.bias = nullptr; e.res = nullptr; e.out = conv; e.ldr = 0; e.ldy = width;
     e.res_dt = LECLIP_F32; e.out_dt = w_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = 0;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
     rc = leclip_gemm_dispatch(workspace, Wp, n_rows, width, Kp, Kp, Kp, e, w_dtype, s);
     if (rc) return rc;
     const dim3 grid((unsigned)((B * T + 3) / 4)), block(256);
-#define LAUNCH_EMB(TI, TO) hipLaunchKernelGGL((embed_ln_pre_kernel<TI, TO>), grid, block, 0, s, (const TI*)conv, class_emb, pos, gamma, beta, (TO*)X, B * T, T, width, eps)
+#define LAUNCH_EMB(TI, TO) hipLaunchKernelGGL((embed_ln_pre_kernel<TI, TO>), grid, block, 0, s, (const TI*)conv, class_emb, pos, gamma, beta, (TO*)X, stats_out, B * T, T, width, eps)
     if (w_dtype == LECLIP_F32) { if (x_dtype != LECLIP_F32) { leclip_set_error("patch_embed_ln: fp32 weights need an fp32 stream"); return LECLIP_E_UNSUPPORTED; } LAUNCH_EMB(float, float); }
     else if (w_dtype == LECLIP_F16) { if (x_dtype == LECLIP_F16) LAUNCH_EMB(f16_t, f16_t); else if (x_dtype == LECLIP_F32) LAUNCH_EMB(f16_t, float); else { leclip_set_error("patch_embed_ln: dtype mix"); return LECLIP_E_UNSUPPORTED; } }
     else { if (x_dtype == LECLIP_BF16) LAUNCH_EMB(bf16_t, bf16_t); else if (x_dtype == LECLIP_F32) LAUNCH_EMB(bf16_t, float); else { leclip_set_error("patch_embed_ln: dtype mix"); return LECLIP_E_UNSUPPORTED; } }
@@ -603,17 +618,19 @@ extern "C" int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, i
     return leclip_check_launch("row_stats_kernel");
 }
 
+int leclip_ln_stats_finalize_launch(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps, hipStream_t s) {
+    const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
+    if (((uintptr_t)partials & 15) == 0 && slots % 2 == 0 && slots <= 2 * LN_MERGE_MAXV)
+        hipLaunchKernelGGL(ln_stats_finalize_kernel, grid, block, 0, s, partials, stats, rows, slots, dim, eps);
+    else
+        hipLaunchKernelGGL(ln_stats_finalize_generic_kernel, grid, block, 0, s, partials, stats, rows, slots, dim, eps);
+    return leclip_check_launch("ln_stats_finalize_kernel");
+}
+
 extern "C" int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
                                             void* stream) {
     if (!partials || !stats || rows <= 0 || slots <= 0 || dim <= 0) { leclip_set_error("ln_stats_finalize: bad argument"); return LECLIP_E_INVALID; }
-    const dim3 grid((unsigned)((rows + 255) / 256)), block(256);
-    hipStream_t s = (hipStream_t)stream;
-    const bool vec = ((uintptr_t)partials & 15) == 0;
-    if (vec && slots == 12) hipLaunchKernelGGL((ln_stats_finalize_kernel<12>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
-    else if (vec && slots == 16) hipLaunchKernelGGL((ln_stats_finalize_kernel<16>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
-    else if (vec && slots == 8) hipLaunchKernelGGL((ln_stats_finalize_kernel<8>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
-    else hipLaunchKernelGGL((ln_stats_finalize_kernel<0>), grid, block, 0, s, partials, stats, rows, slots, dim, eps);
-    return leclip_check_launch("ln_stats_finalize_kernel");
+    return leclip_ln_stats_finalize_launch(partials, stats, rows, slots, dim, eps, (hipStream_t)stream);
 }
 
 extern "C" int leclip_window_aggregate_fwd(const float* global_logits, const float* window_logits, float* out, int64_t B, int W, int C,

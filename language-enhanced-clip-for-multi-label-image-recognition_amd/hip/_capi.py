@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 PACKAGE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libleclip_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU = 0, 1
@@ -38,14 +38,17 @@ SIGNATURES = {
                                              c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "leclip_gemm_ln_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                          c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "leclip_gemm_ln_partials_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_float, c_void_p, c_void_p,
+                                            c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
+                                            c_int, c_int, c_void_p]),
     "leclip_ln_stats_finalize_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
     "leclip_row_stats_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_float, c_int, c_void_p]),
     "leclip_patch_embed_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "leclip_patch_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
                                        c_int, c_int, c_int, c_void_p, c_void_p]),
     "leclip_patch_embed_ln_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int, c_int]),
-    "leclip_patch_embed_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
-                                          c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "leclip_patch_embed_ln_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                          c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "leclip_attention_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int,
                                      c_float, c_int, c_void_p]),
     "leclip_gather_ln_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,

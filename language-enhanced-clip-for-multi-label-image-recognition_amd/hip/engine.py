@@ -83,38 +83,37 @@ class _Workspace:
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
-               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, epilogue_stats: bool = True) -> torch.Tensor:
+               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, have_partials: bool = False) -> torch.Tensor:
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
-    epilogue emits per-row partial sums, a tiny kernel turns them into (mean, rstd), and the consuming GEMM multiplies
-    the raw residual rows by gamma-folded weights and normalises in its epilogue - LN(x) is never written to HBM nor
-    rounded to 16 bits.  The fp32 parity mode and the per-stage taps keep LayerNorm as its own kernel."""
+    epilogue emits per-row block partials (sum, M2 about the block mean per 64 columns), a 5 us merge kernel (launched by
+    the consumer's C entry point) turns them into (mean, rstd), and the consuming GEMM - fed the raw residual rows and
+    gamma-folded weights - normalises in its epilogue: LN(x) is never written to HBM nor rounded to 16 bits.
+    ``have_partials``: ``ws.partials`` already holds the partials of ``x`` (written by the fused
+    patch-embedding / ln_pre pass); otherwise one read-only pass over x provides the first statistics.  The fp32 parity mode and
+    the per-stage taps keep LayerNorm as its own kernel."""
     d = x.shape[1]
     if fuse_ln is None:
         fuse_ln = x.dtype != torch.float32 and taps is None and d % 64 == 0
     if fuse_ln:
-        ops.row_stats(x, out=ws.stats)
+        if have_partials:
+            src = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
+        else:
+            ops.row_stats(x, out=ws.stats)
+            src = dict(ln_stats=ws.stats)
+        after = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
         last = len(blocks) - 1
-        # epilogue_stats: the fused LayerNorm's row statistics come from partial sums written by the producing GEMM's
-        # epilogue (default); False = a read-only pass over the residual stream (kept as a cross-check for tests)
         for i, p in enumerate(blocks):
-            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_stats=ws.stats, ln_colsum=p.cs_qkv, out=ws.qkv)
+            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
             ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
-            if epilogue_stats:
-                ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
-                ops.ln_stats_finalize(ws.partials, d, out=ws.stats)
-            else:
-                ops.gemm(ws.ctx, p.w_o, p.b_o, residual=x, out=x)
-                ops.row_stats(x, out=ws.stats)
-            ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_stats=ws.stats, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u)
-            if i < last and epilogue_stats:
+            ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
+            ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
+            if i < last:
                 ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
-                ops.ln_stats_finalize(ws.partials, d, out=ws.stats)
+                src = after
             else:
                 ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
-                if i < last:
-                    ops.row_stats(x, out=ws.stats)
         return x
     for i, p in enumerate(blocks):
         ops.layernorm(x, p.ln1_w, p.ln1_b, out=ws.h)
@@ -185,10 +184,13 @@ class VisionEngine:
         batch = image.shape[0]
         ws, x, patch_ws, cls_rows = self._workspace(batch)
         image = image.contiguous()
+        have_partials = False
         if taps is None and self.width % 64 == 0 and self.width <= 4096:
-            # patch GEMM with the plain 16-bit epilogue, then class token + positional add + ln_pre in one row-wise pass
+            # patch GEMM with the plain 16-bit epilogue, then class token + positional add + ln_pre in one row-wise pass that also
+            # emits the block partials the first block's fused LayerNorm merges (16-bit modes, width <= 1024)
+            have_partials = self.dtype != torch.float32 and self.width <= 1024
             ops.patch_embed_ln(image, self.wp, self.cls, self.pos, self.ln_pre_w, self.ln_pre_b, self.patch, self.dtype, workspace=patch_ws,
-                               out=x.view(batch, self.tokens, self.width))
+                               out=x.view(batch, self.tokens, self.width), stats_out=ws.partials if have_partials else None)
         else:
             ops.patch_embed(image, self.wp, self.cls, self.pos, self.patch, self.dtype, workspace=patch_ws,
                             out=x.view(batch, self.tokens, self.width))
@@ -197,7 +199,7 @@ class VisionEngine:
             ops.layernorm(x, self.ln_pre_w, self.ln_pre_b, out=x)
             if taps is not None:
                 taps["ln_pre"] = x.float().clone()
-        run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps)
+        run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials)
         return x, batch, cls_rows
 
     def _tail(self, x: torch.Tensor, batch: int, cls_rows, text_features: Optional[torch.Tensor], scale: float, want_features: bool):

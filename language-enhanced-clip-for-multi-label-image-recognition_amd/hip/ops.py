@@ -154,7 +154,7 @@ def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, 
 
 def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor,
                    beta: torch.Tensor, patch: int, x_dtype: torch.dtype, workspace: Optional[torch.Tensor] = None,
-                   out: Optional[torch.Tensor] = None, eps: float = 1e-5):
+                   out: Optional[torch.Tensor] = None, eps: float = 1e-5, stats_out: Optional[torch.Tensor] = None):
     """ln_pre(patch embedding) in three launches: patch extraction, conv GEMM (plain fast epilogue), fused class-token /
     positional add / LayerNorm pass (leclip_patch_embed_ln_fwd)."""
     _dev(image, "image")
@@ -173,7 +173,7 @@ def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tenso
     with _Timed("patch_embed", 2 * npatch * width * 3 * patch * patch,
                 image.numel() * image.element_size() + npatch * wp.shape[1] * wp.element_size() * 2 + 3 * b * t * width * out.element_size()):
         _capi.check(_capi.load().leclip_patch_embed_ln_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(_dev(gamma, "gamma")),
-                                                           _ptr(_dev(beta, "beta")), _ptr(out), b, r, patch, width, dtype_code(image.dtype),
+                                                           _ptr(_dev(beta, "beta")), _ptr(out), _ptr(stats_out), b, r, patch, width, dtype_code(image.dtype),
                                                            dtype_code(wp.dtype), dtype_code(out.dtype), eps, _ptr(workspace), _stream()),
                     "patch_embed_ln")
     return out
@@ -282,9 +282,12 @@ def eot_index(tokens: torch.Tensor):
 def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, ln_stats: Optional[torch.Tensor] = None,
             ln_colsum: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None, act: int = ACT_NONE,
             stats_out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """GEMM with LayerNorm folded around it (see leclip_gemm_ln_fused_fwd): ``ln_stats`` [M,2] (mean, rstd) normalises
-    the A side algebraically, ``stats_out`` [M, N/64, 2] receives the output rows' partial (sum, sum of squares)."""
+            out: Optional[torch.Tensor] = None, ln_partials: Optional[torch.Tensor] = None, ln_stats_ws: Optional[torch.Tensor] = None,
+            eps: float = 1e-5) -> torch.Tensor:
+    """GEMM with LayerNorm folded around it (leclip_gemm_ln_partials_fwd).  The A-side LayerNorm statistics come either as
+    ``ln_stats`` [M,2] (mean, rstd) or as the producer's block partials ``ln_partials`` [M, K/64, 2] (merged inside the GEMM
+    on the 256x256 kernel, through ``ln_stats_ws`` [M,2] otherwise); ``stats_out`` [M, N/64, 2] receives the output rows'
+    block partials (sum, M2 about the block mean) for the next LayerNorm."""
     m, k, lda = _rows2d(a, "a")
     n, kw, ldw = _rows2d(w, "w")
     if k != kw or a.dtype != w.dtype:
@@ -296,16 +299,22 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     if residual is not None:
         _, _, ldr = _rows2d(residual, "residual")
         rdt = dtype_code(residual.dtype)
+    slots = 0
+    if ln_partials is not None:
+        slots = ln_partials.shape[1]
+        if ln_stats_ws is None:
+            ln_stats_ws = torch.empty((m, 2), dtype=torch.float32, device=a.device)
     for name, t, shape in (("ln_stats", ln_stats, (m, 2)), ("ln_colsum", ln_colsum, (n,)), ("stats_out", stats_out, (m, n // 64, 2)),
-                           ("bias", bias, (n,))):
+                           ("bias", bias, (n,)), ("ln_partials", ln_partials, (m, k // 64, 2)), ("ln_stats_ws", ln_stats_ws, (m, 2))):
         if t is not None:
             _dev(t, name)
             assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape, (name, tuple(t.shape), shape)
     nbytes = (m * k + n * k) * a.element_size() + m * n * out.element_size() + (m * n * residual.element_size() if residual is not None else 0)
     with _Timed("gemm", 2 * m * n * k, nbytes):
-        _capi.check(_capi.load().leclip_gemm_ln_fused_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(ln_stats), _ptr(ln_colsum), _ptr(residual),
-                                                          _ptr(out), _ptr(stats_out), m, n, k, lda, ldw, ldr, ldy, act,
-                                                          dtype_code(a.dtype), rdt, dtype_code(out.dtype), _stream()), "gemm_ln")
+        _capi.check(_capi.load().leclip_gemm_ln_partials_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(ln_stats), _ptr(ln_partials), slots,
+                                                             _ptr(ln_stats_ws), eps, _ptr(ln_colsum), _ptr(residual), _ptr(out), _ptr(stats_out),
+                                                             m, n, k, lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
+                                                             dtype_code(out.dtype), _stream()), "gemm_ln")
     return out
 
 
