@@ -221,62 +221,6 @@ struct PP {
     }
 };
 
-// sum over the 8 consecutive lanes that hold one output row (DPP: no LDS round trip)
-__device__ __forceinline__ float row8_sum(float x) {
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
-    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
-    return x;
-}
-
-// Compile-time-specialised 8-wide epilogue step (the hot configurations: output and residual in the operand dtype T, no
-// row remap).  Same arithmetic, in the same order, as epi_chunk8 (leclip_common.h); no branches, no address arithmetic
-// beyond the two pointers handed in, row sums by DPP.
-template <typename T, int PF, int ACT, int STATS>
-__device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[8], const float (&s8)[8], i32x4 res_val,
-                                               f32x2 ln_val, T* optr, float* sptr) {
-    typedef typename VecOf<T>::v8 v8;
-    if constexpr (PF == 2) {
-        const float mean = ln_val[0], rstd = ln_val[1];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, fmaf(-mean, s8[c], v[c]), b8[c]);
-    } else {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += b8[c];
-    }
-    if constexpr (ACT == 1) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = v[c] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[c]));
-    }
-    if constexpr (PF == 1) {
-        const v8 r8 = __builtin_bit_cast(v8, res_val);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
-    }
-    v8 o8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) o8[c] = (T)v[c];
-    *(v8*)optr = o8;
-    if constexpr (STATS == 1) {
-        // (sum, centred sum of squares) of the 64-column block: M2 about the BLOCK mean, so that a large common offset of the
-        // row never enters a difference of two large sums (the consumer merges the blocks with the parallel-variance update)
-        float s1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s1 += (float)o8[c];
-        s1 = row8_sum(s1);
-        const float mb = s1 * (1.0f / 64.0f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { const float dlt = (float)o8[c] - mb; m2 = fmaf(dlt, dlt, m2); }
-        m2 = row8_sum(m2);
-        if ((threadIdx.x & 7) == 0) {
-            f32x2 w;
-            w[0] = s1; w[1] = m2;
-            *(f32x2*)sptr = w;
-        }
-    }
-}
-
 // PF selects what the epilogue prefetches into registers before its first store (compile-time, so that only one
 // prefetch array is ever allocated): 0 nothing, 1 the 16-bit residual of the tile, 2 the fused LayerNorm's (mean, rstd),
 // 3 generic (epilogue operands loaded inside the pass loop).
