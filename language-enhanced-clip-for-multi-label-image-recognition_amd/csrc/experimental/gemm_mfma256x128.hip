@@ -16,7 +16,12 @@
 // t-1 just left  ->  12 ds_read_b128 (8 A + 4 B fragments)  ->  lgkmcnt(0)  ->  32 MFMAs.  One barrier per 32 MFMAs.
 // No pipelining across tiles: after the last step the ring is drained, the epilogue stages through the same LDS, the next tile
 // starts with a two-stage prologue - the bubble is the other workgroup's to fill.
-#include "leclip_common.h"
+// STATUS (round 2): correct (bit-identical to the other families: 68 GEMM / invariance tests green with it dispatched) but SLOWER than
+// the 256x256 kernel in this first form: -5.5 % end to end when it takes the residual shapes (out-proj, c_proj), -13 % when it takes
+// every GEMM (profiles/r02_ab_x2_two_workgroups.txt).  Each wave runs reads -> wait -> 32 MFMAs serially and issues 6 LDS-DMA pieces
+// per 32 MFMAs (1.5x the operand traffic of a 256x256 tile), so a SIMD's two waves cannot keep the matrix pipe above ~80 % even when
+// they interleave perfectly.  Not part of the product library (make x2 builds a variant library for A/B runs).
+#include "../leclip_common.h"
 
 int leclip_cu_count();
 
