@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 4
+#define LECLIP_ABI_VERSION 5
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -220,6 +220,20 @@ int leclip_window_aggregate_fwd(const float* global_logits, const float* window_
 /* Co-occurrence modulation, Caption_distill_double.py:614-618 (adjust_predictions) with the matrix of :632-634:
  * out = p + weight * (p @ Mn), Mn [C, C] = row-normalised(adj / nums[:, None]) built on the host (reference weight 0.5). */
 int leclip_cooccurrence_adjust_fwd(const float* p, const float* Mn, float* out, int64_t B, int C, float weight, void* stream);
+
+/* ---- native byte-level BPE tokenizer (host code).  Replaces SimpleTokenizer.encode / .bpe
+ * (clip/simple_tokenizer.py:62-132) and clip.tokenize (clip/clip.py:185-221): whitespace collapse, lower-casing, the CLIP split
+ * pattern with \p{L} / \p{N} / \s classified exactly as the `regex` module does, the GPT-2 byte alphabet, greedy lowest-rank
+ * merging.  The merge table is the checkpoint-side file bpe_simple_vocab_16e6.txt.gz.  html entities and ftfy's repairs stay on
+ * the caller's side: a text containing '&' (or U+03A3 / U+017F, whose case handling is context dependent) returns
+ * LECLIP_E_UNSUPPORTED and the caller uses its Python path. */
+void* leclip_bpe_open(const char* vocab_gz_path);                 /* NULL on failure: leclip_last_error() */
+void leclip_bpe_close(void* handle);
+int64_t leclip_bpe_vocab_size(void* handle);
+/* ids of `utf8` without SOT / EOT; returns their number (writes at most max_ids) or a negative LECLIP_E_* */
+int64_t leclip_bpe_encode(void* handle, const char* utf8, int64_t* ids, int64_t max_ids);
+/* out [n, context_length] int64 = SOT + ids + EOT, zero padded; too long: error unless `truncate` (then the last kept id is EOT) */
+int leclip_bpe_tokenize(void* handle, const char* const* texts, int64_t n, int context_length, int truncate, int64_t* out);
 
 /* ---- backward of the text tower w.r.t. its ACTIVATIONS (prompt tuning: only the context vectors are trainable, reference
  * trainers/Caption_distill_double.py:762-765, 789-897).  dX of a linear layer is leclip_gemm_bias_act_res_fwd on a

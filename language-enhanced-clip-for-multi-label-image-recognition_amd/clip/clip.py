@@ -44,6 +44,67 @@ def get_tokenizer() -> Optional[SimpleTokenizer]:
     return _tokenizer
 
 
+class NativeTokenizer:
+    """The C++ BPE tokenizer of libleclip_hip.so (csrc/bpe_tokenizer.hip) on the same merge table.  Host code: usable without a
+    GPU.  Texts it refuses (html entities, context-dependent case mapping) raise ``NotImplementedError`` for the caller to route
+    through ``SimpleTokenizer``."""
+
+    def __init__(self, bpe_path: str = None):
+        import ctypes
+        from ..hip import _capi
+        self._lib = _capi.load()
+        self._ct = ctypes
+        path = bpe_path or default_bpe()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"BPE merge table not found at {path}; set LECLIP_BPE_VOCAB")
+        self._h = self._lib.leclip_bpe_open(path.encode())
+        if not self._h:
+            raise RuntimeError(self._lib.leclip_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.leclip_bpe_close(self._h)
+            self._h = None
+
+    def encode(self, text: str) -> List[int]:
+        buf = (self._ct.c_int64 * 512)()
+        n = self._lib.leclip_bpe_encode(self._h, text.encode("utf-8"), buf, 512)
+        if n == -2:
+            raise NotImplementedError(self._lib.leclip_last_error().decode())
+        if n < 0:
+            raise ValueError(self._lib.leclip_last_error().decode())
+        if n > 512:
+            buf = (self._ct.c_int64 * n)()
+            n = self._lib.leclip_bpe_encode(self._h, text.encode("utf-8"), buf, n)
+        return list(buf[:n])
+
+    def tokenize(self, texts: List[str], context_length: int = 77, truncate: bool = False) -> torch.LongTensor:
+        out = torch.zeros(len(texts), context_length, dtype=torch.long)
+        arr = (self._ct.c_char_p * len(texts))(*[t.encode("utf-8") for t in texts])
+        rc = self._lib.leclip_bpe_tokenize(self._h, arr, len(texts), context_length, int(truncate), out.data_ptr())
+        if rc == -2:
+            raise NotImplementedError(self._lib.leclip_last_error().decode())
+        if rc != 0:
+            msg = self._lib.leclip_last_error().decode()
+            raise RuntimeError(msg) if "too long" in msg else ValueError(msg)
+        return out
+
+
+_native: Optional["NativeTokenizer"] = None
+_native_failed = False
+
+
+def get_native_tokenizer() -> Optional["NativeTokenizer"]:
+    """The native tokenizer when both the library and the merge table are there; None otherwise (never an error)."""
+    global _native, _native_failed
+    if _native is None and not _native_failed and os.path.exists(default_bpe()):
+        try:
+            _native = NativeTokenizer()
+        except Exception:
+            _native_failed = True
+    return _native
+
+
 def _cached_ids(text: str) -> List[int]:
     global _prompt_cache
     if _prompt_cache is None:
@@ -58,8 +119,23 @@ def _cached_ids(text: str) -> List[int]:
 
 def encode_text(text: str) -> List[int]:
     """BPE ids of ``text`` without SOT/EOT (``_tokenizer.encode`` in the reference)."""
+    nat = get_native_tokenizer()
+    if nat is not None and "&" not in text and _fix_is_identity(text):
+        try:
+            return nat.encode(text)
+        except NotImplementedError:
+            pass
     tok = get_tokenizer()
     return tok.encode(text) if tok is not None else _cached_ids(text)
+
+
+def _fix_is_identity(text: str) -> bool:
+    """ftfy (when installed) may rewrite non-ASCII text; the native tokenizer does not run it."""
+    try:
+        import ftfy  # noqa: F401
+    except Exception:
+        return True
+    return text.isascii()
 
 
 def tokenize(texts: Union[str, List[str]], context_length: int = 77, truncate: bool = False) -> torch.LongTensor:

@@ -257,3 +257,87 @@ def test_synthetic_caption_set_for_the_entry_point():
     caps, labels = synthetic_captions(coco_object_categories)
     assert caps.shape[1] == 77 and caps.shape[0] == labels.shape[0] and caps.shape[0] % 80 == 0 and labels.shape[1] == 80
     assert bool((labels.sum(1) == 1).all()) and int(caps[:, 0].min()) == 49406 and bool((caps.argmax(-1) > 2).all())
+
+
+# ------------------------------------------------------------------------------------------- native BPE tokenizer (N4)
+def _random_texts(n, seed):
+    rng = np.random.RandomState(seed)
+    pools = ["abcdefghijklmnopqrstuvwxyz", "ABCDEFGHIJKLMNOPQRSTUVWXYZ", "0123456789", " \t\n  ", ".,;:!?'\"-_()[]{}<>|/*+=#@%^~`$",
+             "àéîõüçñßøåæœ", "ÀÉÎÕÜÇÑØÅÆŒǅİ", "αβγδεζηθλμπρστφω", "ΑΒΓΔΛΠΦΩ", "абвгдежзиклмнопрст", "АБВГДЕЖЗ", "中文字符日本語テキスト한국어", "١٢٣४५६๑๒๓ⅷⅻ½¾²³", "😀🎉🚀✨",
+             "'s't're've'm'll'd"]
+    out = []
+    for _ in range(n):
+        parts = []
+        for _ in range(rng.randint(1, 12)):
+            pool = pools[rng.randint(len(pools))]
+            parts.append("".join(pool[rng.randint(len(pool))] for _ in range(rng.randint(1, 9))))
+        out.append("".join(parts))
+    return out
+
+
+def test_native_bpe_matches_python_tokenizer(tmp_path):
+    """csrc/bpe_tokenizer.hip (C ABI leclip_bpe_*) against the Python SimpleTokenizer on the same merge table: a synthetic table
+    written here (so the test needs nothing outside the repo) and 400 random strings over Latin / Greek / Cyrillic / CJK / digits of
+    several scripts / punctuation / emoji / contractions / every kind of whitespace; clip.tokenize's padding, EOT placement,
+    truncation and the too-long error; refusal of html entities."""
+    import gzip
+    from leclip_amd.clip import clip as clipmod
+    from leclip_amd.clip.simple_tokenizer import SimpleTokenizer, byte_alphabet
+    alpha = byte_alphabet()
+    words = ["the", "photo", "of", "a", "person", "cat", "dog", "there", "their", "12", "naïve", "café", "中文", "αβγ", "don't", "...", "!!", "世界"]
+    merges, seen = [], set()
+    for w in words * 3:
+        syms = [alpha[b] for b in w.encode("utf-8")]
+        syms[-1] += "</w>"
+        while len(syms) > 1:                       # left-to-right pair merges: a valid (if arbitrary) merge table
+            pair = (syms[0], syms[1])
+            if pair not in seen:
+                seen.add(pair)
+                merges.append(pair)
+            syms = [syms[0] + syms[1]] + syms[2:]
+    path = tmp_path / "tiny_vocab.txt.gz"
+    with gzip.open(path, "wt", encoding="utf-8") as f:
+        f.write("#version: synthetic\n" + "\n".join(f"{a} {b}" for a, b in merges))
+    py = SimpleTokenizer(str(path))
+    nat = clipmod.NativeTokenizer(str(path))
+    sot, eot = py.encoder["<|startoftext|>"], py.encoder["<|endoftext|>"]
+    assert nat._lib.leclip_bpe_vocab_size(nat._h) == len(py.encoder)
+    texts = [" ".join(words), "A Photo of a PERSON, there!", "<|startoftext|>the cat<|endoftext|>", "  don't   ''' 12345 ½ "] + _random_texts(400, 3)
+    for t in texts:
+        if "&" in t:
+            continue
+        assert nat.encode(t) == py.encode(t), repr(t)
+    with pytest.raises(NotImplementedError):
+        nat.encode("cat &amp; dog")
+    with pytest.raises(NotImplementedError):
+        nat.encode("ΣΟΦΟΣ")                      # final-sigma rule: left to Python
+    short = [t for t in texts if "&" not in t and len(py.encode(t)) <= 75][:50]
+    got = nat.tokenize(short, 77)
+    for row, t in zip(got, short):
+        ids = [sot] + py.encode(t) + [eot]
+        assert row[:len(ids)].tolist() == ids and int(row[len(ids):].abs().sum()) == 0
+    long_text = " ".join(["photo"] * 100)
+    with pytest.raises(RuntimeError):
+        nat.tokenize([long_text], 77)
+    row = nat.tokenize([long_text], 77, truncate=True)[0].tolist()
+    want = ([sot] + py.encode(long_text) + [eot])[:77]
+    want[-1] = eot
+    assert row == want
+
+
+def test_native_bpe_on_the_clip_vocabulary(golden_dir):
+    """With the real merge table (LECLIP_BPE_VOCAB, or the reference's copy when this runs in the build container) the native
+    tokenizer reproduces the token fixtures generated by the reference's tokenizer."""
+    from leclip_amd.clip import clip as clipmod
+    vocab = os.environ.get("LECLIP_BPE_VOCAB") or "/root/reference/project/my_code/clip/bpe_simple_vocab_16e6.txt.gz"
+    if not os.path.exists(vocab):
+        pytest.skip("no CLIP merge table available")
+    nat = clipmod.NativeTokenizer(vocab)
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    names = [str(c).replace("_", " ") for c in t["classnames"]]
+    assert np.array_equal(nat.tokenize([f"a photo of a {c}." for c in names], 77).numpy(), t["tokens_photo"])
+    prefix = " ".join(["X"] * 16)
+    assert np.array_equal(nat.tokenize([prefix + " " + c + "." for c in names], 77, truncate=True).numpy(), t["tokens_ctx16"])
+    extra = [str(s) for s in t["extra_texts"]]
+    keep = [i for i, s in enumerate(extra) if "&" not in s]
+    assert np.array_equal(nat.tokenize([extra[i] for i in keep], 77, truncate=True).numpy(), t["tokens_extra"][keep])
