@@ -111,35 +111,42 @@ struct PP {
     acc4 acc[2][4][4];
     v8 af[4], bfr[4];
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+    int dbg;             // diagnostic build: LECLIP_GEMM_DEBUG bits 8 (no steady-state LDS-DMA), 16 (no MFMA), 32 (no fragment reads)
     unsigned* fine;      // diagnostic build: LDS slot array of this wave for the per-phase timeline of ONE K-tile (null = off)
     int fine_i;
+#define PPDBG(b) (dbg & (b))
 #define FSTAMP()                                                                                                   \
     do {                                                                                                           \
         if (fine) { if ((threadIdx.x & 63) == 0) fine[fine_i] = (unsigned)__builtin_amdgcn_s_memtime(); ++fine_i; } \
     } while (0)
 #else
+#define PPDBG(b) 0
 #define FSTAMP() do { } while (0)
 #endif
 
     __device__ __forceinline__ void stage_a(int stage, int kh, int k_elem) {
         char* slot = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES;
+        if (PPDBG(8)) return;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             __builtin_amdgcn_global_load_lds((const void*)(a_src[u] + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
     }
     __device__ __forceinline__ void stage_b(int stage, int kh, int k_elem) {
         char* slot = smem + stage * STAGE_BYTES + (2 * kh + 1) * SLOT_BYTES;
+        if (PPDBG(8)) return;
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             __builtin_amdgcn_global_load_lds((const void*)(w_src[u] + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
     }
     __device__ __forceinline__ void read_a(int stage, int kh, int rh) {
         const char* p = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES + a_rd + rh * (64 * 64);
+        if (PPDBG(32)) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) af[i] = *(const v8*)(p + i * 1024);
     }
     __device__ __forceinline__ void read_b(int stage, int kh) {
         const char* p = smem + stage * STAGE_BYTES + (2 * kh + 1) * SLOT_BYTES + b_rd;
+        if (PPDBG(32)) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) bfr[j] = *(const v8*)(p + j * 1024);
     }
@@ -151,6 +158,7 @@ struct PP {
         FSTAMP();                                   // fragments in registers
         PIN();
         __builtin_amdgcn_s_setprio(1);
+        if (!PPDBG(16))
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -240,6 +248,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
     p.fine = nullptr;
     p.fine_i = 0;
+    p.dbg = 0;   // set after the first tile's prologue
 #endif
     // fragment reads (v_mfma_f32_16x16x32 operand map): lane l -> row l&15 of a 16-row tile, 16-byte chunk l>>4
     {
@@ -300,6 +309,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     tile_origin(v, m0, n0);
     set_sources(m0, n0);
     prologue();
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+    p.dbg = g.dbg;
+#endif
     // Cross-tile pipelining (see PP::ktile): an even number of K-tiles keeps the stage parity across the tile boundary.
     const bool pipelined = (nk & 1) == 0 && !(DIAG(g.dbg) & 4) && !DIAG(g.no_xtile);
     // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 16 partial-sum pairs)
