@@ -53,10 +53,11 @@ def main():
     ap.add_argument("--arch", default="ViT-B/16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true", help="replay the step from a captured HIP graph on the steps that are not profiled")
-    ap.add_argument("--profile-every", type=int, default=10, help="record per-kernel HIP events on every N-th timed step (0 = never)")
+    ap.add_argument("--profile-every", type=int, default=20, help="record per-kernel HIP events on every N-th timed step (0 = never)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--streams", type=int, default=1, help="split the per-GPU batch over this many HIP streams (kernel tails of one "
-                    "half overlap the other half's kernels)")
+    ap.add_argument("--streams", type=int, default=None, help="parts the image engine runs a large batch as, each on a HIP stream of its own "
+                    "(kernel tails of one part overlap the other's kernels; default: the engine's own, 2)")
+    ap.add_argument("--split", default=None, help="experiments: explicit part sizes, e.g. 144,112")
     ap.add_argument("--mode", default="score", choices=["score", "tune"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
@@ -84,8 +85,6 @@ def main():
     ctx = torch.from_numpy(synth.make_ctx(16, arch.transformer_width, seed=0))
     B = args.batch
     images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(dev)
-    streams = [torch.cuda.Stream() for _ in range(args.streams)] if args.streams > 1 else None
-    parts = list(images.chunk(args.streams)) if streams else None
 
     def fence():
         torch.cuda.synchronize()
@@ -102,24 +101,19 @@ def main():
         cc = CustomCLIP(cfg, coco_object_categories, model)
         with torch.no_grad():
             cc.prompt_learner.ctx.copy_(ctx)
-        return cc.to(dev).eval()
+        cc = cc.to(dev).eval()
+        eng = cc.image_encoder.engine(dev)
+        if args.streams is not None:
+            eng.streams = args.streams
+        if args.split:
+            eng.split_sizes = [int(v) for v in args.split.split(",")]
+        return cc
 
     def measure(cc, steps, warmup, profile_every):
         """W untimed + exactly K timed steps of the hot path, bracketed by barrier + synchronize; max over ranks."""
-        def score_fn(x):
-            if streams is None:
-                return cc(x, if_test=True)[0]
-            cur = torch.cuda.current_stream()
-            outs = []
-            for st, part in zip(streams, parts):
-                st.wait_stream(cur)
-                with torch.cuda.stream(st):
-                    outs.append(cc(part, if_test=True)[0])
-            for st in streams:
-                cur.wait_stream(st)
-            return torch.cat(outs, dim=0)
-
-        scorer = parallel.ShardedScorer(score_fn)
+        eng = cc.image_encoder.engine(dev)
+        run_streams, run_split = eng.streams, eng.split_sizes
+        scorer = parallel.ShardedScorer(lambda x: cc(x, if_test=True)[0])
         step = lambda: scorer.score_local(images)
         with torch.no_grad():
             cc.class_text_features()          # text tower runs once; its features are cached for inference (SURVEY §8d)
@@ -127,7 +121,7 @@ def main():
                 out = step()
             fence()
             graph = None
-            if args.graph and world == 1 and args.streams == 1:
+            if args.graph and world == 1:
                 # the launches of one step captured once (the C-ABI launches go to torch's current stream, which is the
                 # capturing stream here); replayed with one hipGraphLaunch per step
                 graph = torch.cuda.CUDAGraph()
@@ -141,12 +135,16 @@ def main():
                 # each launch costs a few microseconds of GPU idle; sampling keeps the measured rate honest)
                 sampled = profile_every > 0 and i % profile_every == 0
                 ops.set_profile(prof if sampled else None)
+                # a sampled step runs the batch as ONE part, so that an event pair brackets a kernel that has the chip to itself
+                # (with two parts in flight a launch's elapsed time includes the CUs it shares with the other stream's kernel)
+                eng.streams, eng.split_sizes = (1, None) if sampled else (run_streams, run_split)
                 if graph is not None and not sampled:
                     graph.replay()
                     out = gout
                 else:
                     out = step()
             ops.set_profile(None)
+            eng.streams, eng.split_sizes = run_streams, run_split
             fence()
             dt = time.perf_counter() - t0
         if world > 1:
@@ -205,7 +203,7 @@ def main():
         ref_pack = None
     # Companion measurement: BASELINE configs[1] words the config as bf16.  Same kernels, same rate, but bf16 misses the
     # north star's +-0.2 mAP clause, so it is not the headline: its rate and mAP sit beside the fp16 line.
-    if world == 1 and args.dtype == "fp16" and not args.no_second_dtype and args.streams == 1:
+    if world == 1 and args.dtype == "fp16" and not args.no_second_dtype:
         del cc
         cc2 = build("bf16")
         dt2, _ = measure(cc2, args.steps, max(2, args.warmup // 2), 0)

@@ -160,13 +160,90 @@ class VisionEngine:
         self.proj_t = self.proj.t().contiguous()   # [E, d]: K-contiguous B operand of the tail kernel's projection
         self.blocks = pack_blocks(visual.transformer.resblocks, dtype, device)
         self._ws: Dict[int, tuple] = {}
+        # Large batches run as `streams` contiguous parts on HIP streams of their own (the first on the caller's): every big GEMM
+        # is a persistent grid of one workgroup per CU whose last round of tiles leaves most CUs idle (ViT-B/16, B=256: out-proj
+        # and c_proj are 2.31 rounds), and the other part's kernels fill those CUs.  Images are independent and every kernel
+        # is batch-invariant bit for bit, so the split does not change a single output value (tests/test_gpu_parity.py).
+        # Measured (ViT-B/16, img/s one part -> two): B=256 24.1k -> 26.0k, 192 24.6k -> 26.1k, 128 20.4k -> 22.3k, 64 17.6k -> 20.5k,
+        # but 96 24.3k -> 22.8k and 32 15.1k -> 12.1k; ViT-L/14@336 B=128 2 357 -> 2 441.
+        self.streams = 2
+        self.split_min_batch = 128        # from here on two parts always paid; below, only when the tile rounds are badly filled
+        self.split_sizes = None           # experiments: explicit part sizes instead of an even split
+        self._side_streams: list = []
+
+    def _parts(self, image: torch.Tensor):
+        """Row ranges of the stream parts, or None when the batch runs as one piece."""
+        b = image.shape[0]
+        if self.split_sizes is not None:
+            sizes = [int(v) for v in self.split_sizes]
+            if sum(sizes) != b:
+                raise ValueError(f"split_sizes {sizes} do not add up to the batch {b}")
+        elif self.streams > 1 and image.is_cuda and self._split_pays(b):
+            n = min(self.streams, b)
+            sizes = [b // n + (1 if i < b % n else 0) for i in range(n)]
+        else:
+            return None
+        if len(sizes) < 2:
+            return None
+        bounds, lo = [], 0
+        for v in sizes:
+            bounds.append((lo, lo + v))
+            lo += v
+        return bounds
+
+    def _round_fill(self, batch: int) -> float:
+        """Fraction of the CU-rounds of the four block GEMMs that carry a tile when the batch runs as one part (256 x 256 tiles,
+        one persistent workgroup per CU; weights: K)."""
+        d = self.width
+        if d % 256:
+            return 1.0
+        n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
+        tile_rows = (batch * self.tokens + 255) // 256
+        used = total = 0.0
+        for n, k in ((3 * d, 1), (d, 1), (4 * d, 1), (d, 4)):
+            tiles = tile_rows * (n // 256)
+            used += k * tiles / n_cu
+            total += k * ((tiles + n_cu - 1) // n_cu)
+        return used / total
+
+    def _split_pays(self, batch: int) -> bool:
+        if batch >= self.split_min_batch:
+            return True
+        return batch >= 64 and self._round_fill(batch) < 0.8
+
+    def _on_streams(self, image: torch.Tensor, fn):
+        """fn(image part) -> tuple of per-image tensors (or None entries); parts run concurrently, results are concatenated."""
+        bounds = self._parts(image)
+        if bounds is None:
+            return fn(image)
+        cur = torch.cuda.current_stream(self.device)
+        while len(self._side_streams) < len(bounds) - 1:
+            self._side_streams.append(torch.cuda.Stream(device=self.device))
+        side = self._side_streams[:len(bounds) - 1]
+        for st in side:
+            st.wait_stream(cur)                      # fork BEFORE any part is enqueued: the inputs are ready on the caller's stream
+        outs = []
+        for i, (lo, hi) in enumerate(bounds):
+            part = image[lo:hi]
+            if i == 0:
+                outs.append(fn(part))
+                continue
+            with torch.cuda.stream(side[i - 1]):
+                res = fn(part)
+            for t in res:
+                if t is not None:
+                    t.record_stream(cur)             # allocated on the side stream, consumed on the caller's
+            outs.append(res)
+        for st in self._side_streams[:len(bounds) - 1]:
+            cur.wait_stream(st)
+        return tuple(None if outs[0][k] is None else torch.cat([o[k] for o in outs], dim=0) for k in range(len(outs[0])))
 
     def _workspace(self, batch: int):
         # one workspace per (batch size, HIP stream): forwards issued on different streams (batch halves overlapping each
         # other's kernel tails) must not share activation buffers
         key = (batch, torch.cuda.current_stream(self.device).cuda_stream)
         if key not in self._ws:
-            if len(self._ws) >= 4:
+            if len(self._ws) >= 8:
                 self._ws.clear()
             rows = batch * self.tokens
             self._ws[key] = (
@@ -215,8 +292,10 @@ class VisionEngine:
 
     def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         """Image features [B, E] fp32 (VisionTransformer.forward)."""
-        x, batch, cls_rows = self._trunk(image, taps)
-        return self._tail(x, batch, cls_rows, None, 1.0, True)[0]
+        def run(part):
+            x, batch, cls_rows = self._trunk(part, taps)
+            return (self._tail(x, batch, cls_rows, None, 1.0, True)[0],)
+        return run(image)[0] if taps is not None else self._on_streams(image, run)[0]
 
     def dense_features(self, image: torch.Tensor) -> torch.Tensor:
         """[B, T, E] fp32: EVERY token of the last block through ln_post and proj (row 0 = the class token = forward()'s
@@ -238,8 +317,12 @@ class VisionEngine:
 
     def score(self, image: torch.Tensor, text_features: torch.Tensor, scale: float, want_features: bool = False):
         """(features or None, logits [B, C]): the image tower with the cosine-logit contraction folded into its tail kernel."""
-        x, batch, cls_rows = self._trunk(image)
-        return self._tail(x, batch, cls_rows, text_features.float().contiguous(), scale, want_features)
+        tf = text_features.float().contiguous()
+
+        def run(part):
+            x, batch, cls_rows = self._trunk(part)
+            return self._tail(x, batch, cls_rows, tf, scale, want_features)
+        return self._on_streams(image, run)
 
 
 class TextEngine:

@@ -10,8 +10,13 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
-CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-second-dtype"
+# --streams 1: each kernel has the chip to itself, as on the sampled steps bench.py takes its roofline block from (in the default
+# two-part mode a dispatch's begin..end spans the time it shares the CUs with the other stream's kernel); the two-part trace
+# follows as trace2 for the record.
+CMD="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-second-dtype --streams 1"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1 || exit 1
+CMD2="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-second-dtype"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace2 -- $CMD2 > $OUT/trace2.log 2>&1 || exit 1
 echo trace done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT/pmc_fetch.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $CMD > $OUT/pmc_write.log 2>&1 || exit 1

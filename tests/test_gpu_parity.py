@@ -432,6 +432,25 @@ def test_full_batch_properties(ops, dt):
     assert torch.equal(full, ragged)                                        # ragged shards (100 / 87 / 69 images) too
     assert torch.equal(full[200:201], one)                                  # B = 1 == the same image inside B = 256
     assert float(full.abs().max()) <= 4.0 + 1e-4   # |cos| <= 1 scaled by 4
+    # The engine runs B >= 128 as two parts on two HIP streams (kernel tails of one part under the other's kernels): one part,
+    # three parts and an uneven split give the same bits, features included.
+    eng = cc.image_encoder.engine(img.device)
+    assert eng.streams == 2 and eng._parts(img) == [(0, 128), (128, 256)]
+    with torch.no_grad():
+        feats2 = cc.image_encoder(img).clone()
+        try:
+            eng.streams = 1
+            assert eng._parts(img) is None
+            single = cc(img, if_test=True)[0].clone()
+            feats1 = cc.image_encoder(img).clone()
+            eng.streams = 3
+            three = cc(img, if_test=True)[0].clone()
+            eng.split_sizes = [37, 219]
+            uneven = cc(img, if_test=True)[0].clone()
+        finally:
+            eng.streams, eng.split_sizes = 2, None
+    torch.cuda.synchronize()
+    assert torch.equal(full, single) and torch.equal(full, three) and torch.equal(full, uneven) and torch.equal(feats1, feats2)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 0.6)])
