@@ -201,7 +201,7 @@ def main():
                      "measured_on": "the sampled steps of the timed region (1 in %d), which run the batch as ONE part so that each launch has the "
                                     "chip to itself; the other steps run it as %d parts on HIP streams of their own, whose kernels overlap - "
                                     "that is why ms_per_step is below the sum of the kernel times" % (max(args.profile_every, 1), measure.parts),
-                     "one_part_ms_per_step": measure.one_part_ms},
+                     "sampled_step_ms": measure.one_part_ms},   # one part + an event pair around each of its launches
         "kernels": kernels,
         "env_overrides": overrides,
     }
