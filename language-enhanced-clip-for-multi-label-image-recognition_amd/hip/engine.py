@@ -255,9 +255,14 @@ class VisionEngine:
             )
         return self._ws[key]
 
-    def _trunk(self, image: torch.Tensor, taps: Optional[dict] = None):
+    def _check_image(self, image: torch.Tensor):
         if image.dim() != 4 or image.shape[1] != 3 or image.shape[2] != self.resolution or image.shape[3] != self.resolution:
             raise ValueError(f"image must be [B,3,{self.resolution},{self.resolution}], got {tuple(image.shape)}")
+        if not image.is_cuda:
+            raise ValueError("image must live on the HIP device (there is no CPU execution path)")
+
+    def _trunk(self, image: torch.Tensor, taps: Optional[dict] = None):
+        self._check_image(image)
         batch = image.shape[0]
         ws, x, patch_ws, cls_rows = self._workspace(batch)
         image = image.contiguous()
@@ -292,6 +297,10 @@ class VisionEngine:
 
     def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
         """Image features [B, E] fp32 (VisionTransformer.forward)."""
+        if image.shape[0] == 0:   # an empty shard (ragged multi-GPU split): nothing to launch
+            self._check_image(image)
+            return torch.empty((0, self.proj.shape[1]), dtype=torch.float32, device=self.device)
+
         def run(part):
             x, batch, cls_rows = self._trunk(part, taps)
             return (self._tail(x, batch, cls_rows, None, 1.0, True)[0],)
@@ -300,6 +309,9 @@ class VisionEngine:
     def dense_features(self, image: torch.Tensor) -> torch.Tensor:
         """[B, T, E] fp32: EVERY token of the last block through ln_post and proj (row 0 = the class token = forward()'s
         feature, rows 1.. = the patch tokens) - the per-position features of the local branch."""
+        if image.shape[0] == 0:
+            self._check_image(image)
+            return torch.empty((0, self.tokens, self.proj.shape[1]), dtype=torch.float32, device=self.device)
         x, batch, _ = self._trunk(image)
         h = ops.layernorm(x, self.ln_post_w, self.ln_post_b)
         return ops.gemm(h, self.proj_t_padded(), out_dtype=torch.float32)[:, :self.proj.shape[1]].reshape(batch, self.tokens, -1)
@@ -318,6 +330,10 @@ class VisionEngine:
     def score(self, image: torch.Tensor, text_features: torch.Tensor, scale: float, want_features: bool = False):
         """(features or None, logits [B, C]): the image tower with the cosine-logit contraction folded into its tail kernel."""
         tf = text_features.float().contiguous()
+        if image.shape[0] == 0:
+            self._check_image(image)
+            feat = torch.empty((0, self.proj.shape[1]), dtype=torch.float32, device=self.device) if want_features else None
+            return feat, torch.empty((0, tf.shape[0]), dtype=torch.float32, device=self.device)
 
         def run(part):
             x, batch, cls_rows = self._trunk(part)

@@ -584,6 +584,33 @@ def test_dense_clip_local_branch(ops, golden_dir, dt, use_evidence):
     np.testing.assert_allclose(out[1].cpu().numpy(), ref_l.numpy(), atol=tol * max(scale_l, 1e-3) * 2, rtol=0)
 
 
+def test_empty_batch_and_rejected_inputs(ops):
+    """Edge inputs of the image branch: an EMPTY batch (the shard of a rank that got no image) returns [0, C] logits / [0, E] features
+    without a launch, as torch modules do; a CPU tensor or a wrong resolution raises instead of being routed anywhere else."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import CustomCLIP
+    arch = synth.TINY
+    m = _build(arch, 0, "cond", torch.float16).cpu()
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+    cc = CustomCLIP(cfg, coco_object_categories[:7], m).to(DEV).eval()
+    img = torch.from_numpy(synth.make_images(3, arch.image_resolution, seed=1)).to(DEV)
+    with torch.no_grad():
+        full = cc(img, if_test=True)[0]
+        empty = cc(img[:0], if_test=True)[0]
+        one = cc(img[2:3], if_test=True)[0]
+        feats = cc.model.encode_image(img[:0].half())
+        dense = cc.image_encoder.dense_features(img[:0].half())
+        with pytest.raises(RuntimeError, match="HIP device"):
+            cc(img.cpu(), if_test=True)
+        with pytest.raises(ValueError, match="image must be"):
+            cc(img[:, :, :16], if_test=True)
+    assert tuple(empty.shape) == (0, 7) and empty.dtype == full.dtype and empty.device == full.device
+    assert tuple(feats.shape) == (0, arch.embed_dim) and tuple(dense.shape)[0::2] == (0, arch.embed_dim)
+    assert torch.equal(one, full[2:3])
+
+
 def test_train_caption_eval_entry_point(ops):
     from leclip_amd import train_caption
     out = train_caption.main(["--eval-only", "--trainer", "Caption_distill_double", "--backbone", "tiny", "--num-images", "48",
