@@ -14,8 +14,10 @@ target dtype: it meets the +-0.2 mAP clause); the bf16 rate and mAP of the same 
 
 roofline: the dominant kernel family is the MFMA GEMM (96 % of algorithmic FLOPs).  ``achieved`` = algorithmic
 FLOPs of the GEMM launches of one step / their summed duration, from HIP events recorded around every GEMM launch
-on the launch stream inside the timed region; ``peak`` = 2516.6 TFLOP/s dense bf16/fp16 MFMA (256 CU x 2.4 GHz x
-4096 FLOP/clk/CU).  cpu_baseline: the CPU oracle (oracle/clip_oracle.py, torch-CPU fp32 restatement pinned to the
+on the launch stream inside the timed region - on its sampled steps (--profile-every), which run the batch as ONE part: the
+other steps run it as two halves on two HIP streams whose kernels overlap (hip/engine.py), so an event
+pair around a launch would include the time it shares the chip; ``peak`` = 2516.6 TFLOP/s dense bf16/fp16 MFMA (256 CU x
+2.4 GHz x 4096 FLOP/clk/CU).  cpu_baseline: the CPU oracle (oracle/clip_oracle.py, torch-CPU fp32 restatement pinned to the
 reference) timed on the host cores on a bounded sample, rank 0, N=1 only.
 """
 import argparse
