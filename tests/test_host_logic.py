@@ -341,3 +341,21 @@ def test_native_bpe_on_the_clip_vocabulary(golden_dir):
     extra = [str(s) for s in t["extra_texts"]]
     keep = [i for i, s in enumerate(extra) if "&" not in s]
     assert np.array_equal(nat.tokenize([extra[i] for i in keep], 77, truncate=True).numpy(), t["tokens_extra"][keep])
+
+
+def test_stream_part_rule():
+    """hip/engine.py stream_parts: which batches the image engine runs as two halves on two HIP streams (pure host logic)."""
+    from leclip_amd.hip.engine import round_fill, stream_parts
+    vb = dict(tokens=197, width=768, n_cu=256)
+    assert stream_parts(256, 2, None, 128, **vb) == [(0, 128), (128, 256)]
+    assert stream_parts(255, 2, None, 128, **vb) == [(0, 128), (128, 255)]
+    assert stream_parts(256, 3, None, 128, **vb) == [(0, 86), (86, 171), (171, 256)]
+    assert stream_parts(256, 1, None, 128, **vb) is None
+    assert stream_parts(96, 2, None, 128, **vb) is None and stream_parts(32, 2, None, 128, **vb) is None      # measured losses
+    assert stream_parts(64, 2, None, 128, **vb) == [(0, 32), (32, 64)]                                          # rounds filled to 0.70
+    assert abs(round_fill(64, **vb) - 0.703) < 2e-3 and abs(round_fill(96, **vb) - 0.867) < 2e-3 and abs(round_fill(256, **vb) - 0.866) < 2e-3
+    assert round_fill(8, tokens=17, width=128, n_cu=256) == 1.0                                                  # tiny towers: no 256-wide tiles
+    assert stream_parts(256, 2, [37, 219], 128, **vb) == [(0, 37), (37, 256)]
+    assert stream_parts(5, 2, [5, 0], 128, **vb) is None
+    with pytest.raises(ValueError):
+        stream_parts(256, 2, [100, 100], 128, **vb)
