@@ -60,6 +60,10 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="parts the image engine runs a large batch as, each on a HIP stream of its own "
                     "(kernel tails of one part overlap the other's kernels; default: the engine's own, 2)")
     ap.add_argument("--split", default=None, help="experiments: explicit part sizes, e.g. 144,112")
+    ap.add_argument("--last-block", default="full", choices=["full", "class-token"],
+                    help="full (default): the last residual block is computed for every token, as the reference does and as the algorithmic "
+                         "FLOP count of the metric assumes.  class-token: the engine's own default outside this benchmark - only what "
+                         "ln_post(x[:, 0]) consumes (same logits bit for bit, 6 %% fewer FLOPs executed); its rate is reported beside the headline")
     ap.add_argument("--mode", default="score", choices=["score", "tune"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
@@ -109,6 +113,7 @@ def main():
             eng.streams = args.streams
         if args.split:
             eng.split_sizes = [int(v) for v in args.split.split(",")]
+        eng.cls_last_block = args.last_block == "class-token"
         return cc
 
     def measure(cc, steps, warmup, profile_every):
@@ -216,6 +221,19 @@ def main():
             result["mAP"]["accuracy_gate"] = "met (|mAP - oracle| <= 0.2)"
     else:
         ref_pack = None
+    # Companion measurement: the engine's own default computes, in the LAST residual block, only what the class token needs (identical
+    # logits, tests/test_gpu_parity.py::test_full_batch_properties; 6 % fewer FLOPs executed).  The headline above keeps the whole block,
+    # like the reference and like the FLOP count its fractions use; this is the rate a user of the package gets.
+    if world == 1 and args.last_block == "full" and not args.no_second_dtype:
+        eng = cc.image_encoder.engine(dev)
+        eng.cls_last_block = True
+        dt3, _ = measure(cc, args.steps, max(2, args.warmup // 2), 0)
+        eng.cls_last_block = False
+        L, t, d = arch.vision_layers, arch.vision_tokens, arch.vision_width
+        skipped = 2 * d * d * (t - 1) + 4 * t * (t - 1) * d + 2 * d * d * (t - 1) + 16 * d * d * (t - 1)   # q of the other rows, their attention, out-proj, MLP
+        result["class_token_last_block"] = {"value": B * args.steps / dt3, "unit": "img/s", "ms_per_step": dt3 / args.steps * 1e3, "steps": args.steps,
+                                            "flops_per_image_executed": fpi - skipped + 2 * d * d * (t - 1),   # (the qkv GEMM still runs whole)
+                                            "note": "engine default outside this benchmark; logits bit-identical to the headline run's"}
     # Companion measurement: BASELINE configs[1] words the config as bf16.  Same kernels, same rate, but bf16 misses the
     # north star's +-0.2 mAP clause, so it is not the headline: its rate and mAP sit beside the fp16 line.
     if world == 1 and args.dtype == "fp16" and not args.no_second_dtype:

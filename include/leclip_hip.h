@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 5
+#define LECLIP_ABI_VERSION 6
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -123,6 +123,16 @@ int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* cl
 int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
                          int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale,
                          leclip_dtype dtype, void* stream);
+
+/* The same for the FIRST q_rows query rows of every (batch, head) only (q_rows = 0 or T: all of them = leclip_attention_fwd); keys and
+ * values are still the whole sequence.  Rows are computed in blocks of 32 (F32: singly) by the same code as the full call, so a
+ * computed row has the same bits in both; out rows q_rows .. up to the end of the last block may be written (same values as the full
+ * call would give them), the rest of out is not touched.  The reference has no such call: its last residual block
+ * (clip/model.py:207-228 inside :266) computes every token although VisionTransformer.forward keeps the class token alone
+ * (`ln_post(x[:, 0, :])`, :271) - the image engine uses this for that block. */
+int leclip_attention_prefix_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
+                                int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale, int q_rows,
+                                leclip_dtype dtype, void* stream);
 
 /* out[i, :] = LayerNorm(x[row_index[i], :]) @ proj        proj [dim, E] row-major (the reference's `x @ proj`)
  * Replaces clip/model.py:271-274 (ln_post(x[:,0,:]) @ proj) and clip/model.py:388-390 /

@@ -21,6 +21,8 @@ struct AttnArgs {
     int64_t ld_qkv, ld_out;
     float scale_log2e;  // scale * log2(e)
     int causal;
+    int q_rows;         // 0: every query row; n > 0: only the first n query rows of every (batch, head) are computed and stored
+                        // (leclip_attention_prefix_fwd: the last block of the image tower needs the class token's row only)
 };
 
 // One 32-query block of one (batch, head): S^T = K.Q^T, masked softmax over keys, O^T = V^T.P^T, store.
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
     }
     __syncthreads();
 
-    const int nqb = (a.T + 31) >> 5;
+    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5;   // (a block is computed whole: with q_rows = 1, rows 0..31 are stored)
     T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
     for (int qb = wave; qb < nqb; qb += 4) {
         v8 qf[4];
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     for (int i = 0; i < 2; ++i)
         vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
 
-    const int nqb = (a.T + 31) >> 5, nchunk = TP >> 7;
+    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5, nchunk = TP >> 7;
     T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
     for (int qb = wave; qb < nqb; qb += 8) {
         v8 qf[4];
@@ -505,7 +507,8 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a, int v_global)
     const float scale = a.scale_log2e * 0.6931471805599453f;
     float* myP = sP + wave * TPAD;
     constexpr int NKK = (F32_TMAX_VG + 63) / 64;
-    for (int q = wave; q < a.T; q += 4) {
+    const int q_end = a.q_rows > 0 && a.q_rows < a.T ? a.q_rows : a.T;
+    for (int q = wave; q < q_end; q += 4) {
         const float qd = base[(int64_t)q * a.ld_qkv + lane];   // q[d = lane]
         const int klimit = a.causal ? q : a.T - 1;
         float sloc[NKK];
@@ -558,7 +561,7 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     constexpr int force_pipe = -1;
 #endif
     const bool pipe_ok = a.T > 192 && a.T <= 224;   // 7 query blocks for 8 waves
-    if (pipe_ok && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
+    if (pipe_ok && a.q_rows == 0 && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
         const int n_cu = leclip_cu_count();
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
         constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
@@ -587,6 +590,13 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
 extern "C" int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
                                     int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale,
                                     leclip_dtype dtype, void* stream) {
+    return leclip_attention_prefix_fwd(qkv, out, B, T, heads, head_dim, ld_qkv, ld_out, mask, scale, 0, dtype, stream);
+}
+
+extern "C" int leclip_attention_prefix_fwd(const void* qkv, void* out, int64_t B, int T, int heads, int head_dim,
+                                           int64_t ld_qkv, int64_t ld_out, leclip_mask mask, float scale, int q_rows,
+                                           leclip_dtype dtype, void* stream) {
+    if (q_rows < 0 || q_rows > T) { leclip_set_error("attention: q_rows %d outside [0, T=%d]", q_rows, T); return LECLIP_E_INVALID; }
     if (!qkv || !out || B <= 0 || T <= 0 || heads <= 0 || ld_qkv < 3 * heads * 64 || ld_out < heads * 64) {
         leclip_set_error("attention: null pointer or inconsistent sizes");
         return LECLIP_E_INVALID;
@@ -599,6 +609,7 @@ extern "C" int leclip_attention_fwd(const void* qkv, void* out, int64_t B, int T
     AttnArgs a;
     a.qkv = qkv; a.out = out; a.T = T; a.heads = heads; a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
+    a.q_rows = q_rows == T ? 0 : q_rows;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LECLIP_F32) {
         if (T > F32_TMAX_VG) { leclip_set_error("attention(f32): T=%d > %d", T, F32_TMAX_VG); return LECLIP_E_UNSUPPORTED; }

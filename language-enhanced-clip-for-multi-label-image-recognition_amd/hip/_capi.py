@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 PACKAGE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libleclip_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU = 0, 1
@@ -51,6 +51,8 @@ SIGNATURES = {
                                           c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
     "leclip_attention_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int,
                                      c_float, c_int, c_void_p]),
+    "leclip_attention_prefix_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int64, c_int64, c_int,
+                                            c_float, c_int, c_int, c_void_p]),
     "leclip_gather_ln_proj_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int,
                                           c_int, c_int64, c_float, c_int, c_int, c_void_p]),
     "leclip_l2norm_logits_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),

@@ -72,7 +72,7 @@ def pack_blocks(resblocks, dtype: torch.dtype, device):
 class _Workspace:
     """Activation buffers of one tower for one (batch, tokens) shape."""
 
-    def __init__(self, rows: int, d: int, dtype: torch.dtype, device):
+    def __init__(self, rows: int, d: int, dtype: torch.dtype, device, batch: int = 0):
         self.h = torch.empty((rows, d), dtype=dtype, device=device)
         self.qkv = torch.empty((rows, 3 * d), dtype=dtype, device=device)
         self.ctx = torch.empty((rows, d), dtype=dtype, device=device)
@@ -80,10 +80,16 @@ class _Workspace:
         # fused-LayerNorm path: per-row (mean, rstd) and the epilogue's partial sums per 64-column block
         self.stats = torch.empty((rows, 2), dtype=torch.float32, device=device)
         self.partials = torch.empty((rows, d // 64, 2), dtype=torch.float32, device=device)
+        if batch > 0:   # image tower: the last block's class-token rows (run_blocks, ``cls_last``)
+            self.cls_x = torch.empty((batch, d), dtype=dtype, device=device)
+            self.cls_u = torch.empty((batch, 4 * d), dtype=dtype, device=device)
+            self.cls_stats = torch.empty((batch, 2), dtype=torch.float32, device=device)
+            self.cls_partials = torch.empty((batch, d // 64, 2), dtype=torch.float32, device=device)
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
-               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, have_partials: bool = False) -> torch.Tensor:
+               taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, have_partials: bool = False,
+               cls_last: bool = False) -> torch.Tensor:
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
@@ -92,7 +98,14 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
     gamma-folded weights - normalises in its epilogue: LN(x) is never written to HBM nor rounded to 16 bits.
     ``have_partials``: ``ws.partials`` already holds the partials of ``x`` (written by the fused
     patch-embedding / ln_pre pass); otherwise one read-only pass over x provides the first statistics.  The fp32 parity mode and
-    the per-stage taps keep LayerNorm as its own kernel."""
+    the per-stage taps keep LayerNorm as its own kernel.
+
+    ``cls_last`` (image tower, fused path): VisionTransformer.forward keeps ``x[:, 0, :]`` alone (clip/model.py:271), so in the LAST
+    block only the class token's row has a consumer.  Keys and values still need every token (the qkv GEMM runs whole), but the
+    attention computes the first query block only, and out-proj, LayerNorm 2, c_fc, QuickGELU and c_proj run on the B class rows
+    (read in place at their stride T*d, written compactly).  Rows are independent in every one of these kernels and both GEMM
+    families produce the same bits, so the class rows equal the full computation's bit for bit
+    (tests/test_gpu_parity.py::test_full_batch_properties); returned is the compact [B, d] class-row block instead of x."""
     d = x.shape[1]
     if fuse_ln is None:
         fuse_ln = x.dtype != torch.float32 and taps is None and d % 64 == 0
@@ -106,6 +119,15 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
         last = len(blocks) - 1
         for i, p in enumerate(blocks):
             ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
+            if cls_last and i == last:
+                ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx, q_rows=1)
+                ctx_c = ws.ctx.view(batch, tokens * d)[:, :d]      # class rows in place: [B, d] with row stride T*d
+                x_c = x.view(batch, tokens * d)[:, :d]
+                cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
+                ops.gemm_ln(ctx_c, p.w_o, p.b_o, residual=x_c, stats_out=ws.cls_partials, out=ws.cls_x)
+                ops.gemm_ln(ws.cls_x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.cls_u, **cls)
+                ops.gemm(ws.cls_u, p.w_pr, p.b_pr, residual=ws.cls_x, out=ws.cls_x)
+                return ws.cls_x
             ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
             ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
             ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
@@ -204,6 +226,9 @@ class VisionEngine:
         # Measured (ViT-B/16, img/s one part -> two): B=256 24.1k -> 26.0k, 192 24.6k -> 26.1k, 128 20.4k -> 22.3k, 64 17.6k -> 20.5k,
         # but 96 24.3k -> 22.8k and 32 15.1k -> 12.1k; ViT-L/14@336 B=128 2 357 -> 2 441.
         self.streams = 2
+        # forward() / score() consume the class token alone: the last block computes only what that row needs (run_blocks, cls_last:
+        # the whole qkv GEMM, attention for the first query block, out-proj / MLP on B rows instead of B*T) - same bits, 6 % less time.
+        self.cls_last_block = True
         self.split_min_batch = 128        # from here on two parts always paid; below, only when the tile rounds are badly filled
         self.split_sizes = None           # experiments: explicit part sizes instead of an even split
         self._side_streams: list = []
@@ -251,7 +276,7 @@ class VisionEngine:
                 self._ws.clear()
             rows = batch * self.tokens
             self._ws[key] = (
-                _Workspace(rows, self.width, self.dtype, self.device),
+                _Workspace(rows, self.width, self.dtype, self.device, batch=batch),
                 torch.empty((rows, self.width), dtype=self.dtype, device=self.device),
                 torch.empty(ops._capi.load().leclip_patch_embed_ln_workspace_bytes(batch, self.resolution, self.patch, self.width,
                                                                                    ops.dtype_code(self.dtype)), dtype=torch.uint8, device=self.device),
@@ -265,7 +290,9 @@ class VisionEngine:
         if not image.is_cuda:
             raise ValueError("image must live on the HIP device (there is no CPU execution path)")
 
-    def _trunk(self, image: torch.Tensor, taps: Optional[dict] = None):
+    def _trunk(self, image: torch.Tensor, taps: Optional[dict] = None, cls_only: bool = False):
+        """-> (rows, batch, class-row indices, class-row stride).  ``cls_only``: the caller consumes the class token alone, so the
+        last block may compute just that (``self.cls_last_block``); rows is then the compact [B, d] class-row block."""
         self._check_image(image)
         batch = image.shape[0]
         ws, x, patch_ws, cls_rows = self._workspace(batch)
@@ -285,17 +312,21 @@ class VisionEngine:
             ops.layernorm(x, self.ln_pre_w, self.ln_pre_b, out=x)
             if taps is not None:
                 taps["ln_pre"] = x.float().clone()
-        run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials)
-        return x, batch, cls_rows
+        cls_last = (cls_only and self.cls_last_block and taps is None and self.dtype != torch.float32 and self.width % 64 == 0
+                    and self.width <= 1024 and self.proj.shape[1] % 16 == 0)     # (the conditions of the fused path and of the tail kernel)
+        rows = run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials, cls_last=cls_last)
+        if cls_last:
+            return rows, batch, None, self.width
+        return x, batch, cls_rows, self.tokens * self.width
 
-    def _tail(self, x: torch.Tensor, batch: int, cls_rows, text_features: Optional[torch.Tensor], scale: float, want_features: bool):
+    def _tail(self, x: torch.Tensor, batch: int, cls_rows, row_stride: int, text_features: Optional[torch.Tensor], scale: float,
+              want_features: bool):
         # ln_post on the class token only, then @ proj (clip/model.py:271-274) and - when text features are given - the
         # normalised, scaled cosine logits (model.py:399-404): ONE launch, both contractions on the matrix cores
         # (leclip_image_tail_fwd).  The class rows sit at a fixed stride (T*d) and are read in place.
         e = self.proj.shape[1]
         if self.width % 64 == 0 and self.width <= 1024 and e % 16 == 0:
-            return ops.image_tail(x, batch, self.tokens * self.width, self.ln_post_w, self.ln_post_b, self.proj_t, text_features, scale,
-                                  want_features)
+            return ops.image_tail(x, batch, row_stride, self.ln_post_w, self.ln_post_b, self.proj_t, text_features, scale, want_features)
         feat = ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)     # odd widths (tiny test towers)
         return feat, (ops.l2norm_logits(feat, text_features, scale) if text_features is not None else None)
 
@@ -306,8 +337,8 @@ class VisionEngine:
             return torch.empty((0, self.proj.shape[1]), dtype=torch.float32, device=self.device)
 
         def run(part):
-            x, batch, cls_rows = self._trunk(part, taps)
-            return (self._tail(x, batch, cls_rows, None, 1.0, True)[0],)
+            x, batch, cls_rows, stride = self._trunk(part, taps, cls_only=True)
+            return (self._tail(x, batch, cls_rows, stride, None, 1.0, True)[0],)
         return run(image)[0] if taps is not None else self._on_streams(image, run)[0]
 
     def dense_features(self, image: torch.Tensor) -> torch.Tensor:
@@ -316,7 +347,7 @@ class VisionEngine:
         if image.shape[0] == 0:
             self._check_image(image)
             return torch.empty((0, self.tokens, self.proj.shape[1]), dtype=torch.float32, device=self.device)
-        x, batch, _ = self._trunk(image)
+        x, batch, _, _ = self._trunk(image)
         h = ops.layernorm(x, self.ln_post_w, self.ln_post_b)
         return ops.gemm(h, self.proj_t_padded(), out_dtype=torch.float32)[:, :self.proj.shape[1]].reshape(batch, self.tokens, -1)
 
@@ -340,8 +371,8 @@ class VisionEngine:
             return feat, torch.empty((0, tf.shape[0]), dtype=torch.float32, device=self.device)
 
         def run(part):
-            x, batch, cls_rows = self._trunk(part)
-            return self._tail(x, batch, cls_rows, tf, scale, want_features)
+            x, batch, cls_rows, stride = self._trunk(part, cls_only=True)
+            return self._tail(x, batch, cls_rows, stride, tf, scale, want_features)
         return self._on_streams(image, run)
 
 

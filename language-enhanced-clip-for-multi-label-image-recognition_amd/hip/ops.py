@@ -180,7 +180,9 @@ def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tenso
 
 
 def attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, causal: bool = False,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, q_rows: int = 0) -> torch.Tensor:
+    """q_rows > 0: only the first q_rows query rows of every (batch, head) are computed (leclip_attention_prefix_fwd); the rest of
+    ``out`` is left as it is."""
     rows, width3, ld = _rows2d(qkv, "qkv")
     d = heads * 64
     if rows != batch * tokens or width3 != 3 * d:
@@ -188,10 +190,11 @@ def attention(qkv: torch.Tensor, batch: int, tokens: int, heads: int, causal: bo
     if out is None:
         out = torch.empty((rows, d), dtype=qkv.dtype, device=qkv.device)
     _, _, ldo = _rows2d(out, "out")
-    with _Timed("attention", 4 * batch * heads * tokens * tokens * 64, rows * 4 * d * qkv.element_size()):
-        _capi.check(_capi.load().leclip_attention_fwd(_ptr(qkv), _ptr(out), batch, tokens, heads, 64, ld, ldo,
-                                                      MASK_CAUSAL if causal else MASK_NONE, 0.125, dtype_code(qkv.dtype),
-                                                      _stream()), "attention")
+    nq = q_rows if q_rows > 0 else tokens
+    with _Timed("attention", 4 * batch * heads * nq * tokens * 64, (rows * 2 * d + batch * nq * 2 * d) * qkv.element_size()):
+        _capi.check(_capi.load().leclip_attention_prefix_fwd(_ptr(qkv), _ptr(out), batch, tokens, heads, 64, ld, ldo,
+                                                             MASK_CAUSAL if causal else MASK_NONE, 0.125, int(q_rows),
+                                                             dtype_code(qkv.dtype), _stream()), "attention")
     return out
 
 

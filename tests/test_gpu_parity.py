@@ -451,6 +451,16 @@ def test_full_batch_properties(ops, dt):
             eng.streams, eng.split_sizes = 2, None
     torch.cuda.synchronize()
     assert torch.equal(full, single) and torch.equal(full, three) and torch.equal(full, uneven) and torch.equal(feats1, feats2)
+    # The last block computes only what the class token needs (run_blocks cls_last): same bits as the block computed for every token.
+    assert eng.cls_last_block
+    with torch.no_grad():
+        try:
+            eng.cls_last_block = False
+            whole = cc(img, if_test=True)[0].clone()
+            feats_whole = cc.image_encoder(img).clone()
+        finally:
+            eng.cls_last_block = True
+    assert torch.equal(full, whole) and torch.equal(feats2, feats_whole)
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 0.6)])
@@ -582,6 +592,28 @@ def test_dense_clip_local_branch(ops, golden_dir, dt, use_evidence):
     np.testing.assert_allclose(out[0].cpu().numpy(), ref_g.numpy(), atol=tol, rtol=0)
     scale_l = float(ref_l.abs().max())
     np.testing.assert_allclose(out[1].cpu().numpy(), ref_l.numpy(), atol=tol * max(scale_l, 1e-3) * 2, rtol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,T,h,causal", [(3, 50, 2, False), (2, 77, 8, True), (4, 197, 12, False), (1, 577, 16, False)])
+def test_attention_prefix(ops, dt, B, T, h, causal):
+    """leclip_attention_prefix_fwd: the first q_rows query rows of every (batch, head) have the bits of the full call; rows past the
+    last computed block are not touched."""
+    g = torch.Generator().manual_seed(5)
+    qkv = (torch.randn(B * T, 3 * h * 64, generator=g) * 0.7).to(dt).to(DEV)
+    full = ops.attention(qkv, B, T, h, causal)
+    for q_rows in (1, 33):
+        if q_rows > T:
+            continue
+        out = torch.full_like(full, 7.0)
+        ops.attention(qkv, B, T, h, causal, out=out, q_rows=q_rows)
+        got, ref = out.view(B, T, -1), full.view(B, T, -1)
+        assert torch.equal(got[:, :q_rows], ref[:, :q_rows])
+        blk = 1 if dt == torch.float32 else 32
+        end = min(T, (q_rows + blk - 1) // blk * blk)
+        assert bool((got[:, end:] == 7.0).all())
+    with pytest.raises(Exception):
+        ops.attention(qkv, B, T, h, causal, q_rows=T + 1)
 
 
 def test_empty_batch_and_rejected_inputs(ops):
