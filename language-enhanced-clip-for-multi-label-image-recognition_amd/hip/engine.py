@@ -85,6 +85,7 @@ class _Workspace:
             self.cls_u = torch.empty((batch, 4 * d), dtype=dtype, device=device)
             self.cls_stats = torch.empty((batch, 2), dtype=torch.float32, device=device)
             self.cls_partials = torch.empty((batch, d // 64, 2), dtype=torch.float32, device=device)
+            self.cls_index = (torch.arange(batch, device=device, dtype=torch.int64) * (rows // batch)).contiguous()
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
@@ -101,8 +102,8 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
     the per-stage taps keep LayerNorm as its own kernel.
 
     ``cls_last`` (image tower, fused path): VisionTransformer.forward keeps ``x[:, 0, :]`` alone (clip/model.py:271), so in the LAST
-    block only the class token's row has a consumer.  Keys and values still need every token (the qkv GEMM runs whole), but the
-    attention computes the first query block only, and out-proj, LayerNorm 2, c_fc, QuickGELU and c_proj run on the B class rows
+    block only the class token's row has a consumer.  Keys and values still need every token (the k|v two thirds of the qkv GEMM run on
+    all rows, the q third on the class rows), the attention computes the first query block only, and out-proj, LayerNorm 2, c_fc, QuickGELU and c_proj run on the B class rows
     (read in place at their stride T*d, written compactly).  Rows are independent in every one of these kernels and both GEMM
     families produce the same bits, so the class rows equal the full computation's bit for bit
     (tests/test_gpu_parity.py::test_full_batch_properties); returned is the compact [B, d] class-row block instead of x."""
@@ -118,16 +119,23 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
         after = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
         last = len(blocks) - 1
         for i, p in enumerate(blocks):
-            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
             if cls_last and i == last:
-                ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx, q_rows=1)
-                ctx_c = ws.ctx.view(batch, tokens * d)[:, :d]      # class rows in place: [B, d] with row stride T*d
-                x_c = x.view(batch, tokens * d)[:, :d]
+                x_c = x.view(batch, tokens * d)[:, :d]             # class rows in place: [B, d] with row stride T*d
                 cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
+                if "ln_partials" in src:
+                    # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only
+                    ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
+                    ops.gather_rows(ws.partials.view(batch * tokens, -1), ws.cls_index, out=ws.cls_partials.view(batch, -1))
+                    ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], **cls)
+                else:   # (a one-block tower without fused patch statistics: the whole qkv GEMM)
+                    ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
+                ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx, q_rows=1)
+                ctx_c = ws.ctx.view(batch, tokens * d)[:, :d]
                 ops.gemm_ln(ctx_c, p.w_o, p.b_o, residual=x_c, stats_out=ws.cls_partials, out=ws.cls_x)
                 ops.gemm_ln(ws.cls_x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.cls_u, **cls)
                 ops.gemm(ws.cls_u, p.w_pr, p.b_pr, residual=ws.cls_x, out=ws.cls_x)
                 return ws.cls_x
+            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
             ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
             ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
             ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)

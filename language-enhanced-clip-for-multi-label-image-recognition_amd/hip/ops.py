@@ -453,12 +453,15 @@ def l2norm_logits_bwd(img: torch.Tensor, txt: torch.Tensor, dlogits: torch.Tenso
     return out
 
 
-def gather_rows(src: torch.Tensor, index: torch.Tensor) -> torch.Tensor:
+def gather_rows(src: torch.Tensor, index: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """src[index] for a 2-D row-major tensor (device-side row copy, no ATen indexing kernel)."""
     rows, dim, ld = _rows2d(src, "src")
     assert index.dtype == torch.int64 and index.is_contiguous()
-    out = torch.empty((index.numel(), dim), dtype=src.dtype, device=src.device)
-    _capi.check(_capi.load().leclip_gather_rows_fwd(_ptr(src), _ptr(_dev(index, "index")), _ptr(out), index.numel(), dim, ld, dim,
+    if out is None:
+        out = torch.empty((index.numel(), dim), dtype=src.dtype, device=src.device)
+    _, odim, ldo = _rows2d(out, "out")
+    assert odim == dim and out.dtype == src.dtype and out.shape[0] == index.numel()
+    _capi.check(_capi.load().leclip_gather_rows_fwd(_ptr(src), _ptr(_dev(index, "index")), _ptr(out), index.numel(), dim, ld, ldo,
                                                     dtype_code(src.dtype), _stream()), "gather_rows")
     return out
 
