@@ -225,20 +225,29 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
     const int d_model = a.heads * 64;
     const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
 
-    // ---- stage K and V: 8 threads x 16 B per 128-byte row, 32 rows per pass
-    for (int r = tid >> 3; r < TP; r += 32) {
+    // ---- stage K and V: 8 threads x 16 B per 128-byte row, 32 rows per pass; all 2*NKT loads of a thread are issued before the
+    // first LDS write (with one pass in flight at a time the prefix call, which computes a single query block, was bound by this loop)
+    {
         const int c = tid & 7;
-        v8 kv, vv;
-        if (r < a.T) {
-            const T* row = base + (int64_t)r * a.ld_qkv;
-            kv = *(const v8*)(row + d_model + c * 8);
-            vv = *(const v8*)(row + 2 * d_model + c * 8);
-        } else {
+        v8 kv[NKT], vv[NKT];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { kv[i] = (T)0.f; vv[i] = (T)0.f; }
+        for (int u = 0; u < NKT; ++u) {
+            const int r = (tid >> 3) + 32 * u;
+            const int gr = r < a.T ? r : a.T - 1;   // (rows past T are zeroed below; the clamped load keeps the loop branch-free)
+            const T* row = base + (int64_t)gr * a.ld_qkv;
+            kv[u] = *(const v8*)(row + d_model + c * 8);
+            vv[u] = *(const v8*)(row + 2 * d_model + c * 8);
         }
-        *(v8*)(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
-        *(v8*)(sV + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vv;
+#pragma unroll
+        for (int u = 0; u < NKT; ++u) {
+            const int r = (tid >> 3) + 32 * u;
+            if (r >= a.T) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { kv[u][i] = (T)0.f; vv[u][i] = (T)0.f; }
+            }
+            *(v8*)(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv[u];
+            *(v8*)(sV + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vv[u];
+        }
     }
     __syncthreads();
 
