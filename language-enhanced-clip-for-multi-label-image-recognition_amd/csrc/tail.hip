@@ -44,48 +44,56 @@ struct TailArgs {
 
 constexpr int TAIL_MAXV = 4;   // d <= 1024
 
-// proj GEMM for one wave: column tiles wave, wave + 4, ... (16 columns each, at most PT_MAX per wave), A = LayerNorm output in
-// LDS.  K is the OUTER loop: the B fragments of all of the wave's tiles for a k-step are independent 16-byte loads straight
-// from L2 (proj^T is 0.8 MB, shared by every workgroup), requested one k-step ahead of the MFMAs that consume them.
-constexpr int PT_MAX = 12;   // E <= 768 per 4 waves
+// Workgroup shape: TAIL_NW waves (1 024 threads) share 16 images.  The kernel is a latency chain - strided class rows from HBM, then
+// proj^T (0.8 MB) and the text features from L2 - run by ceil(B / 16) workgroups, so what shortens it is more loads in flight per
+// workgroup: 16 waves take one LayerNorm row each, 2 - 3 projection column tiles each with the B fragments FOUR k-steps ahead, one
+// logit tile each (round 2: 58 us -> see profiles).
+constexpr int TAIL_NW = 16;
+// proj GEMM for one wave: column tiles wave, wave + TAIL_NW, ... (16 columns each, at most PT_MAX per wave), A = LayerNorm output
+// in LDS.  K is the OUTER loop: the B fragments of all of the wave's tiles for a k-step are independent 16-byte loads straight
+// from L2 (proj^T is shared by every workgroup), requested PT_DEPTH - 1 k-steps ahead of the MFMAs that consume them.
+constexpr int PT_MAX = 3;     // E <= 768 per 16 waves
+constexpr int PT_DEPTH = 4;
 template <typename T>
 __device__ __forceinline__ void proj_tiles(const TailArgs& a, const char* sh, int hpitch, float* sfeat, int fpitch, int wave, int lane) {
     typedef typename VecOf<T>::v8 v8;
     const int fr = lane & 15, fc = lane >> 4;
     const int ntiles = a.E >> 4;
-    const int mine = (ntiles - wave + 3) >> 2;            // tiles of this wave
+    const int mine = (ntiles - wave + TAIL_NW - 1) / TAIL_NW;    // tiles of this wave
     const T* prow = (const T*)a.proj_t + (int64_t)(wave * 16 + fr) * a.d + fc * 8;
-    const int64_t tstride = (int64_t)64 * a.d;            // wave's next tile: 4 tiles = 64 proj^T rows further
+    const int64_t tstride = (int64_t)(16 * TAIL_NW) * a.d;       // wave's next tile: TAIL_NW tiles further
     const char* hrow = sh + fr * hpitch + fc * 16;
+    const int nsteps = a.d >> 5;                                 // k-steps of 32
     acc4 acc[PT_MAX];
-    v8 bq[2][PT_MAX];
+    v8 bq[PT_DEPTH][PT_MAX];
 #pragma unroll
     for (int i = 0; i < PT_MAX; ++i) acc[i] = acc4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[0][i] = *(const v8*)(prow + i * tstride);
-    for (int k = 0; k < a.d; k += 64) {                   // d % 64 == 0: two k-steps per iteration, static buffer indices
+    for (int u = 0; u < PT_DEPTH - 1; ++u)
+        if (u < nsteps) {
 #pragma unroll
-        for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[1][i] = *(const v8*)(prow + i * tstride + k + 32);
-        {
-            const v8 af = *(const v8*)(hrow + k * 2);
-#pragma unroll
-            for (int i = 0; i < PT_MAX; ++i) if (i < mine) acc[i] = mfma16(af, bq[0][i], acc[i]);
+            for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[u][i] = *(const v8*)(prow + i * tstride + u * 32);
         }
-        if (k + 64 < a.d) {
+    for (int s0 = 0; s0 < nsteps; s0 += PT_DEPTH) {
 #pragma unroll
-            for (int i = 0; i < PT_MAX; ++i) if (i < mine) bq[0][i] = *(const v8*)(prow + i * tstride + k + 64);
-        }
-        {
-            const v8 af = *(const v8*)(hrow + (k + 32) * 2);
+        for (int u = 0; u < PT_DEPTH; ++u) {                     // static ring slots: step s0 + u lives in slot u
+            const int st = s0 + u;
+            if (st >= nsteps) break;
+            if (st + PT_DEPTH - 1 < nsteps) {
 #pragma unroll
-            for (int i = 0; i < PT_MAX; ++i) if (i < mine) acc[i] = mfma16(af, bq[1][i], acc[i]);
+                for (int i = 0; i < PT_MAX; ++i)
+                    if (i < mine) bq[(u + PT_DEPTH - 1) % PT_DEPTH][i] = *(const v8*)(prow + i * tstride + (st + PT_DEPTH - 1) * 32);
+            }
+            const v8 af = *(const v8*)(hrow + st * 64);
+#pragma unroll
+            for (int i = 0; i < PT_MAX; ++i) if (i < mine) acc[i] = mfma16(af, bq[u][i], acc[i]);
         }
     }
 #pragma unroll
     for (int i = 0; i < PT_MAX; ++i)
         if (i < mine) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) sfeat[(4 * fc + r) * fpitch + (wave + 4 * i) * 16 + fr] = acc[i][r];
+            for (int r = 0; r < 4; ++r) sfeat[(4 * fc + r) * fpitch + (wave + TAIL_NW * i) * 16 + fr] = acc[i][r];
         }
 }
 template <>
@@ -94,7 +102,7 @@ __device__ __forceinline__ void proj_tiles<float>(const TailArgs& a, const char*
     // four operands of a group are 16 contiguous bytes on both sides
     const int fr = lane & 15, fq = lane >> 4;
     const float* P = (const float*)a.proj_t;
-    for (int nt = wave; nt * 16 < a.E; nt += 4) {
+    for (int nt = wave; nt * 16 < a.E; nt += TAIL_NW) {
         acc4 acc = {0.f, 0.f, 0.f, 0.f};
         const float* prow = P + (int64_t)(nt * 16 + fr) * a.d + 4 * fq;
         const char* hrow = sh + fr * hpitch + 16 * fq;
@@ -111,7 +119,7 @@ __device__ __forceinline__ void proj_tiles<float>(const TailArgs& a, const char*
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
+__global__ __launch_bounds__(TAIL_NW * 64) void image_tail_kernel(TailArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -123,10 +131,11 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
     float* stnorm = sinorm + 16;                           // [C]            |text feature|^2
     const int64_t b0 = (int64_t)blockIdx.x * 16;
 
-    // ---- ln_post on the class-token rows: one wave per row, 4 rows per wave; two-pass fp32 statistics (as layernorm_kernel)
+    // ---- ln_post on the class-token rows: one wave per row; two-pass fp32 statistics (as layernorm_kernel)
     const int nv = a.d >> 8, tail = a.d & 255;
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave * 4 + rr;
+    constexpr int RPW = 16 / TAIL_NW;   // rows per wave
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
         int64_t b = b0 + row;
         b = b < a.B ? b : a.B - 1;
         const T* xr = (const T*)a.x + b * a.row_stride;
@@ -157,7 +166,7 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
     }
     // |t_c|^2 of the text features (every workgroup needs all C of them: 0.16 MB from L2); four rows per wave in flight
     if (a.txt) {
-        for (int c0 = wave * 4; c0 < a.C; c0 += 16) {
+        for (int c0 = wave * 4; c0 < a.C; c0 += 4 * TAIL_NW) {
             float s4[4] = {0.f, 0.f, 0.f, 0.f};
             for (int k = lane * 4; k < a.E; k += 256) {
                 f32x4 t[4];
@@ -175,8 +184,8 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
     // ---- features = LN(x_cls) @ proj on the matrix cores
     proj_tiles<T>(a, sh, hpitch, sfeat, fpitch, wave, lane);
     __syncthreads();
-    for (int rr = 0; rr < 4; ++rr) {
-        const int row = wave * 4 + rr;
+    for (int rr = 0; rr < RPW; ++rr) {
+        const int row = wave * RPW + rr;
         const float* fr_ = sfeat + row * fpitch;
         float s = 0.f;
         for (int k = lane * 4; k < a.E; k += 256) {
@@ -192,7 +201,7 @@ __global__ __launch_bounds__(256) void image_tail_kernel(TailArgs a) {
 
     // ---- logits[b, c] = scale * <f_b, t_c> / (|f_b| |t_c|): exact-fp32 MFMA, K in groups of 16 (slot q <-> k = 16g + 4q + j)
     const int fr = lane & 15, fq = lane >> 4;
-    for (int ct = wave; ct * 16 < a.C; ct += 4) {
+    for (int ct = wave; ct * 16 < a.C; ct += TAIL_NW) {
         int c = ct * 16 + fr;
         const int cc = c < a.C ? c : a.C - 1;
         const float* trow = a.txt + (int64_t)cc * a.E + 4 * fq;
@@ -354,7 +363,7 @@ int launch_tail(const TailArgs& a, hipStream_t s) {
     const int lds = 16 * (a.d * (int)sizeof(T) + 16) + (16 * (a.E + 4) + 16 + a.C) * 4;
     static bool attr_set[LECLIP_MAX_DEVICES] = {};
     leclip_set_max_lds(image_tail_kernel<T>, 160 * 1024, attr_set);
-    hipLaunchKernelGGL((image_tail_kernel<T>), dim3((unsigned)((a.B + 15) / 16)), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((image_tail_kernel<T>), dim3((unsigned)((a.B + 15) / 16)), dim3(TAIL_NW * 64), lds, s, a);
     return leclip_check_launch("image_tail_kernel");
 }
 
@@ -369,8 +378,8 @@ extern "C" int leclip_image_tail_fwd(const void* x, const float* gamma, const fl
     }
     if (!dtype_ok(dtype)) { leclip_set_error("image_tail: bad dtype"); return LECLIP_E_INVALID; }
     const int kq = dtype == LECLIP_F32 ? 16 : 32;
-    if (dim % 64 != 0 || dim > 256 * TAIL_MAXV || dim % kq != 0 || E % 16 != 0 || E > 64 * PT_MAX || C > 4096) {
-        leclip_set_error("image_tail: dim=%d must be a multiple of 64 and <= %d, E=%d a multiple of 16 (<= %d), C=%d <= 4096", dim, 256 * TAIL_MAXV, E, 64 * PT_MAX, C);
+    if (dim % 64 != 0 || dim > 256 * TAIL_MAXV || dim % kq != 0 || E % 16 != 0 || E > 16 * TAIL_NW * PT_MAX || C > 4096) {
+        leclip_set_error("image_tail: dim=%d must be a multiple of 64 and <= %d, E=%d a multiple of 16 (<= %d), C=%d <= 4096", dim, 256 * TAIL_MAXV, E, 16 * TAIL_NW * PT_MAX, C);
         return LECLIP_E_UNSUPPORTED;
     }
     const int esz = dtype_size(dtype);
