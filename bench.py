@@ -230,7 +230,7 @@ def main():
         dt3, _ = measure(cc, args.steps, max(2, args.warmup // 2), 0)
         eng.cls_last_block = False
         t, d = arch.vision_tokens, arch.vision_width
-        skipped = (t - 1) * (18 * d * d + 4 * t * d)   # the other rows' out-proj (2 d^2), MLP (16 d^2) and attention (4 T d); the qkv GEMM runs whole
+        skipped = (t - 1) * (20 * d * d + 4 * t * d)   # the other rows' q projection (2 d^2), out-proj (2 d^2), MLP (16 d^2) and attention (4 T d)
         result["class_token_last_block"] = {"value": B * args.steps / dt3, "unit": "img/s", "ms_per_step": dt3 / args.steps * 1e3, "steps": args.steps,
                                             "flops_per_image_executed": fpi - skipped,
                                             "note": "engine default outside this benchmark; logits bit-identical to the headline run's"}
