@@ -166,12 +166,12 @@ def main():
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt = float(tmax.item())
         assert out.shape == (world * B, 80) and bool(torch.isfinite(out).all())
-        measure.one_part_ms = sum(a.elapsed_time(b) for a, b in sampled_ev) / len(sampled_ev) if sampled_ev else None
-        measure.parts = len(eng._parts(images) or [None])
-        return dt, prof
+        info = {"sampled_step_ms": sum(a.elapsed_time(b) for a, b in sampled_ev) / len(sampled_ev) if sampled_ev else None,
+                "parts": len(eng._parts(images) or [None])}
+        return dt, prof, info
 
     cc = build(args.dtype)
-    dt, prof = measure(cc, args.steps, args.warmup, args.profile_every)
+    dt, prof, run_info = measure(cc, args.steps, args.warmup, args.profile_every)
 
     # per-kernel-family durations from the HIP events recorded inside the timed region
     fam = {}
@@ -197,7 +197,7 @@ def main():
         "config": {"workload": f"{args.arch} image tower + 80 learnable-prompt class features (cached) -> x4.0 cosine logits, "
                                f"B={B}/GPU {args.dtype}, inference-only (BASELINE configs[1]; configs[3] at 8 GPUs)",
                    "global_batch": world * B, "parallelism": f"dp{world}" + ("+allgather(logits)" if world > 1 else ""),
-                   "flops_per_image": fpi, "stream_parts": measure.parts},
+                   "flops_per_image": fpi, "stream_parts": run_info["parts"]},
         "end_to_end_tflops_per_gpu": ips / world * fpi * 1e-12,
         "end_to_end_mfma_frac": ips / world * fpi * 1e-12 / PEAK_MFMA_TFLOPS,
         "roofline": {"bound": "mfma", "kernel": ops._capi.load().leclip_gemm_kernel_name(B * arch.vision_tokens, arch.vision_width,
@@ -207,8 +207,8 @@ def main():
                      "flops_per_launch": g[1] / max(g[3], 1), "avg_launch_us": g[0] / max(g[3], 1) * 1e6,
                      "measured_on": "the sampled steps of the timed region (1 in %d), which run the batch as ONE part so that each launch has the "
                                     "chip to itself; the other steps run it as %d parts on HIP streams of their own, whose kernels overlap - "
-                                    "that is why ms_per_step is below the sum of the kernel times" % (max(args.profile_every, 1), measure.parts),
-                     "sampled_step_ms": measure.one_part_ms},   # one part + an event pair around each of its launches
+                                    "that is why ms_per_step is below the sum of the kernel times" % (max(args.profile_every, 1), run_info["parts"]),
+                     "sampled_step_ms": run_info["sampled_step_ms"]},   # one part + an event pair around each of its launches
         "kernels": kernels,
         "env_overrides": overrides,
     }
@@ -227,7 +227,7 @@ def main():
     if world == 1 and args.last_block == "full" and not args.no_second_dtype:
         eng = cc.image_encoder.engine(dev)
         eng.cls_last_block = True
-        dt3, _ = measure(cc, args.steps, max(2, args.warmup // 2), 0)
+        dt3, _, _ = measure(cc, args.steps, max(2, args.warmup // 2), 0)
         eng.cls_last_block = False
         t, d = arch.vision_tokens, arch.vision_width
         skipped = (t - 1) * (20 * d * d + 4 * t * d)   # the other rows' q projection (2 d^2), out-proj (2 d^2), MLP (16 d^2) and attention (4 T d)
@@ -239,7 +239,7 @@ def main():
     if world == 1 and args.dtype == "fp16" and not args.no_second_dtype:
         del cc
         cc2 = build("bf16")
-        dt2, _ = measure(cc2, args.steps, max(2, args.warmup // 2), 0)
+        dt2, _, _ = measure(cc2, args.steps, max(2, args.warmup // 2), 0)
         comp = {"value": B * args.steps / dt2, "unit": "img/s", "ms_per_step": dt2 / args.steps * 1e3, "steps": args.steps}
         if ref_pack is not None:
             comp["mAP"] = score_against(ref_pack, cc2, arch, dev)
