@@ -21,6 +21,9 @@ struct AttnArgs {
     int64_t ld_qkv, ld_out;
     float scale_log2e;  // scale * log2(e)
     int causal;
+#ifdef LECLIP_DIAG
+    WgLog wglog;
+#endif
     int q_rows;         // 0: every query row; n > 0: only the first n query rows of every (batch, head) are computed and stored
                         // (leclip_attention_prefix_fwd: the last block of the image tower needs the class token's row only)
 };
@@ -314,6 +317,10 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     const char* qrd = sQ + (lane & 31) * 128;
     const int qsw = ((lane & 31) >> 1) & 7, qh = lane >> 5;
 
+#ifdef LECLIP_DIAG
+    unsigned long long wl_t0 = 0;
+    if (a.wglog.buf && tid == 0) wl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     int hd = blockIdx.x;
     const bool active = wave * 32 < a.T;   // wave-uniform
     {
@@ -350,6 +357,9 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
         }
         hd = nxt;
     }
+#ifdef LECLIP_DIAG
+    if (a.wglog.buf && tid == 0) wglog_end(a.wglog, 0x200u, wl_t0);
+#endif
 }
 
 // ---------------------------------------------------------------- streaming kernel for long sequences (ViT-L/14@336: T = 577)
@@ -619,6 +629,9 @@ extern "C" int leclip_attention_prefix_fwd(const void* qkv, void* out, int64_t B
     a.qkv = qkv; a.out = out; a.T = T; a.heads = heads; a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
     a.q_rows = q_rows == T ? 0 : q_rows;
+#ifdef LECLIP_DIAG
+    a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
+#endif
     hipStream_t s = (hipStream_t)stream;
     if (dtype == LECLIP_F32) {
         if (T > F32_TMAX_VG) { leclip_set_error("attention(f32): T=%d > %d", T, F32_TMAX_VG); return LECLIP_E_UNSUPPORTED; }

@@ -35,3 +35,10 @@ extern "C" const char* leclip_strerror(int code) {
         default: return "unknown error";
     }
 }
+
+#ifdef LECLIP_DIAG
+unsigned long long* g_leclip_wglog = nullptr;
+unsigned g_leclip_wglog_cap = 0, g_leclip_wglog_seq = 0;
+// diagnostic library only: device buffer of 2 + 4 * cap u64 (zeroed by the caller) that the GEMM / attention workgroups append to
+extern "C" void leclip_diag_set_wglog(void* device_buf, unsigned cap) { g_leclip_wglog = (unsigned long long*)device_buf; g_leclip_wglog_cap = cap; g_leclip_wglog_seq = 0; }
+#endif

@@ -57,6 +57,9 @@ struct Gemm256Args {
     EpiParams epi;
     int tiles_n, tiles_total;
     int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
+#ifdef LECLIP_DIAG
+    WgLog wglog;
+#endif
     unsigned long long* stamps;   // diagnostic build (-DLECLIP_GEMM_STAMPS) only: s_memtime stamps, [workgroup][16 tiles][8]
     int no_xtile;      // 1: do not pipeline the K-loop across output tiles (LECLIP_GEMM_NO_XTILE, A/B timing)
     int strict_wait;   // 1: never relax the first K-tile's vmcnt waits past the previous epilogue's stores (A/B timing)
@@ -265,6 +268,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     const int dma_r = lane >> 2;
     const int nk = g.K / TK;   // >= 2 (checked by the host)
     const EpiParams& e = g.epi;
+#ifdef LECLIP_DIAG
+    unsigned long long wl_t0 = 0;
+    if (g.wglog.buf && tid == 0) wl_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     auto tile_origin = [&](int v, int64_t& m0, int& n0) {
         const int tile = xcd_remap256(v, g.tiles_total);
@@ -682,6 +689,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (!more) break;
         v = vn;
     }
+#ifdef LECLIP_DIAG
+    if (g.wglog.buf && tid == 0) wglog_end(g.wglog, 0x100u + (unsigned)(PF * 16 + (CFG & 15)), wl_t0);
+#endif
 }
 
 template <typename T, int PF, int CFG>
@@ -765,6 +775,7 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     static const int desync = [] { const char* e = getenv("LECLIP_GEMM_DESYNC"); return e ? atoi(e) : 0; }();
     a.desync = desync;
     a.stamps = g_stamps;
+    a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
     static const int no_xtile = [] { const char* e = getenv("LECLIP_GEMM_NO_XTILE"); return e ? atoi(e) : 0; }();
     a.no_xtile = no_xtile;
     static const int strict_wait = [] { const char* e = getenv("LECLIP_GEMM_STRICT_WAIT"); return e ? atoi(e) : 0; }();

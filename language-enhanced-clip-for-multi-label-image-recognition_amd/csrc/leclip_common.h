@@ -15,6 +15,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 
+// Diagnostic library only (make diag): per-workgroup begin / end times on the 100 MHz real-time counter, appended to a device log
+// (leclip_diag_set_wglog) - the occupancy timeline of overlapping launches (profiles/two_part_timeline.py).  The product build
+// compiles none of it.
+#ifdef LECLIP_DIAG
+struct WgLog { unsigned long long* buf; unsigned cap; unsigned seq; };   // buf[0] = entry count, entries of 4 u64 from buf[2]
+extern unsigned long long* g_leclip_wglog;
+extern unsigned g_leclip_wglog_cap, g_leclip_wglog_seq;
+__device__ __forceinline__ void wglog_end(const WgLog& w, unsigned tag, unsigned long long t0) {
+    const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long i = atomicAdd(w.buf, 1ull);
+    if (i < w.cap) {
+        unsigned long long* e = w.buf + 2 + 4 * i;
+        unsigned hw, xcc;   // where the workgroup ran: HW_ID (se / sh / cu fields) and XCC_ID
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        e[0] = ((unsigned long long)tag << 32) | blockIdx.x; e[1] = t0; e[2] = t1;
+        e[3] = w.seq | ((unsigned long long)(hw & 0xffff) << 32) | ((unsigned long long)(xcc & 0xf) << 48);
+    }
+}
+#endif
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <typename T> struct VecOf;
