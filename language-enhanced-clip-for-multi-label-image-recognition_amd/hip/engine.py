@@ -254,24 +254,22 @@ class VisionEngine:
         if bounds is None:
             return fn(image)
         cur = torch.cuda.current_stream(self.device)
-        while len(self._side_streams) < len(bounds) - 1:
+        # every part on a stream of the engine's own, created one after the other (the runtime spreads consecutive streams over its
+        # hardware queues; the caller's stream may share a queue with one of them, which would serialise the two parts)
+        while len(self._side_streams) < len(bounds):
             self._side_streams.append(torch.cuda.Stream(device=self.device))
-        side = self._side_streams[:len(bounds) - 1]
+        side = self._side_streams[:len(bounds)]
         for st in side:
             st.wait_stream(cur)                      # fork BEFORE any part is enqueued: the inputs are ready on the caller's stream
         outs = []
-        for i, (lo, hi) in enumerate(bounds):
-            part = image[lo:hi]
-            if i == 0:
-                outs.append(fn(part))
-                continue
-            with torch.cuda.stream(side[i - 1]):
-                res = fn(part)
+        for st, (lo, hi) in zip(side, bounds):
+            with torch.cuda.stream(st):
+                res = fn(image[lo:hi])
             for t in res:
                 if t is not None:
-                    t.record_stream(cur)             # allocated on the side stream, consumed on the caller's
+                    t.record_stream(cur)             # allocated on the part's stream, consumed on the caller's
             outs.append(res)
-        for st in self._side_streams[:len(bounds) - 1]:
+        for st in side:
             cur.wait_stream(st)
         return tuple(None if outs[0][k] is None else torch.cat([o[k] for o in outs], dim=0) for k in range(len(outs[0])))
 
