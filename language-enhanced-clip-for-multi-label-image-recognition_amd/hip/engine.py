@@ -103,8 +103,8 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
 
     ``cls_last`` (image tower, fused path): VisionTransformer.forward keeps ``x[:, 0, :]`` alone (clip/model.py:271), so in the LAST
     block only the class token's row has a consumer.  Keys and values still need every token (the k|v two thirds of the qkv GEMM run on
-    all rows, the q third on the class rows), the attention computes the first query block only, and out-proj, LayerNorm 2, c_fc, QuickGELU and c_proj run on the B class rows
-    (read in place at their stride T*d, written compactly).  Rows are independent in every one of these kernels and both GEMM
+    all rows, the q third on the class rows), the attention computes the first query block only, and out-proj, LayerNorm 2, c_fc,
+    QuickGELU and c_proj run on the B class rows (read in place at their stride T*d, written compactly).  Rows are independent in every one of these kernels and both GEMM
     families produce the same bits, so the class rows equal the full computation's bit for bit
     (tests/test_gpu_parity.py::test_full_batch_properties); returned is the compact [B, d] class-row block instead of x."""
     d = x.shape[1]
