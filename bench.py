@@ -29,6 +29,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# The image engine runs the two halves of a batch on two HIP streams, which only overlap when they sit on different hardware queues.  The
+# runtime has 4 by default and shares them among every stream in use (null stream, the two part streams, RCCL's): room for the rest.
+# Must be set before the HIP runtime starts; measured equal to the default on one GPU (profiles/r02_ab_stream_parts.txt).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 PEAK_MFMA_TFLOPS = 2516.6
 PEAK_HBM_GBS = 8000.0

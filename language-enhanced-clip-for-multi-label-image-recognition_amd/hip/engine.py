@@ -202,6 +202,22 @@ def stream_parts(batch: int, streams: int, split_sizes, split_min_batch: int, to
     return bounds
 
 
+_PART_STREAMS: Dict[int, list] = {}
+
+
+def _part_streams(device, n: int):
+    """The HIP streams the parts of a batch run on: ONE set per device for the whole process, none of them the caller's.  The runtime
+    has a handful of hardware queues (GPU_MAX_HW_QUEUES, 4 by default) and hands them to streams as they come into use; two parts whose
+    streams share a queue run one after the other (measured: a second engine with streams of its own fell from 26.5 k to 21.2 k img/s,
+    the rate of GPU_MAX_HW_QUEUES=1), so every engine uses the same few streams."""
+    idx = torch.device(device).index
+    idx = torch.cuda.current_device() if idx is None else idx
+    pool = _PART_STREAMS.setdefault(idx, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 class VisionEngine:
     """VisionTransformer.forward (clip/model.py:259-276) as a HIP kernel sequence."""
 
@@ -239,7 +255,6 @@ class VisionEngine:
         self.cls_last_block = True
         self.split_min_batch = 128        # from here on two parts always paid; below, only when the tile rounds are badly filled
         self.split_sizes = None           # experiments: explicit part sizes instead of an even split
-        self._side_streams: list = []
 
     def _parts(self, image: torch.Tensor):
         """Row ranges of the stream parts, or None when the batch runs as one piece."""
@@ -254,11 +269,7 @@ class VisionEngine:
         if bounds is None:
             return fn(image)
         cur = torch.cuda.current_stream(self.device)
-        # every part on a stream of the engine's own, created one after the other (the runtime spreads consecutive streams over its
-        # hardware queues; the caller's stream may share a queue with one of them, which would serialise the two parts)
-        while len(self._side_streams) < len(bounds):
-            self._side_streams.append(torch.cuda.Stream(device=self.device))
-        side = self._side_streams[:len(bounds)]
+        side = _part_streams(self.device, len(bounds))
         for st in side:
             st.wait_stream(cur)                      # fork BEFORE any part is enqueued: the inputs are ready on the caller's stream
         outs = []
