@@ -145,11 +145,12 @@ def main():
                 fence()
             prof = []
             sampled_ev = []
+            sample_at = min(profile_every // 2, steps // 2) if profile_every > 0 else 0   # mid-run: clocks and caches in their steady state
             t0 = time.perf_counter()
             for i in range(steps):
                 # per-kernel HIP events on every `profile_every`-th step of the timed region (a pair of event records around
                 # each launch costs a few microseconds of GPU idle; sampling keeps the measured rate honest)
-                sampled = profile_every > 0 and i % profile_every == 0
+                sampled = profile_every > 0 and i % profile_every == sample_at
                 ops.set_profile(prof if sampled else None)
                 # a sampled step runs the batch as ONE part, so that an event pair brackets a kernel that has the chip to itself
                 # (with two parts in flight a launch's elapsed time includes the CUs it shares with the other stream's kernel)
@@ -191,7 +192,8 @@ def main():
         f[3] += 1
     g = fam.get("gemm", [1e-9, 0, 0, 1])
     gemm_tflops = g[1] / g[0] * 1e-12
-    prof_steps = len(range(0, args.steps, args.profile_every)) if args.profile_every > 0 else 1
+    off = min(args.profile_every // 2, args.steps // 2) if args.profile_every > 0 else 0
+    prof_steps = len([i for i in range(args.steps) if i % args.profile_every == off]) if args.profile_every > 0 else 1
     kernels = {k: {"launches_per_step": v[3] // prof_steps, "avg_us": v[0] / v[3] * 1e6,
                    "tflops": v[1] / v[0] * 1e-12, "alg_gbs": v[2] / v[0] * 1e-9} for k, v in fam.items()}
 
