@@ -318,8 +318,8 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     const int qsw = ((lane & 31) >> 1) & 7, qh = lane >> 5;
 
 #ifdef LECLIP_DIAG
-    unsigned long long wl_t0 = 0;
-    if (a.wglog.buf && tid == 0) wl_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wl_t0 = 0, wl_c0 = 0;
+    if (a.wglog.buf && tid == 0) { wl_t0 = __builtin_amdgcn_s_memrealtime(); wl_c0 = __builtin_amdgcn_s_memtime(); }
 #endif
     int hd = blockIdx.x;
     const bool active = wave * 32 < a.T;   // wave-uniform
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
         hd = nxt;
     }
 #ifdef LECLIP_DIAG
-    if (a.wglog.buf && tid == 0) wglog_end(a.wglog, 0x200u, wl_t0);
+    if (a.wglog.buf && tid == 0) wglog_end(a.wglog, 0x200u, wl_t0, wl_c0);
 #endif
 }
 

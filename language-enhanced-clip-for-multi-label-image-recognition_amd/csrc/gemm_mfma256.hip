@@ -269,8 +269,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     const int nk = g.K / TK;   // >= 2 (checked by the host)
     const EpiParams& e = g.epi;
 #ifdef LECLIP_DIAG
-    unsigned long long wl_t0 = 0;
-    if (g.wglog.buf && tid == 0) wl_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long wl_t0 = 0, wl_c0 = 0;
+    if (g.wglog.buf && tid == 0) { wl_t0 = __builtin_amdgcn_s_memrealtime(); wl_c0 = __builtin_amdgcn_s_memtime(); }
 #endif
 
     auto tile_origin = [&](int v, int64_t& m0, int& n0) {
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         v = vn;
     }
 #ifdef LECLIP_DIAG
-    if (g.wglog.buf && tid == 0) wglog_end(g.wglog, 0x100u + (unsigned)(PF * 16 + (CFG & 15)), wl_t0);
+    if (g.wglog.buf && tid == 0) wglog_end(g.wglog, 0x100u + (unsigned)(PF * 16 + (CFG & 15)), wl_t0, wl_c0);
 #endif
 }
 

@@ -19,19 +19,22 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // (leclip_diag_set_wglog) - the occupancy timeline of overlapping launches (profiles/two_part_timeline.py).  The product build
 // compiles none of it.
 #ifdef LECLIP_DIAG
-struct WgLog { unsigned long long* buf; unsigned cap; unsigned seq; };   // buf[0] = entry count, entries of 4 u64 from buf[2]
+struct WgLog { unsigned long long* buf; unsigned cap; unsigned seq; };   // buf[0] = entry count, entries of 6 u64 from buf[2]
 extern unsigned long long* g_leclip_wglog;
 extern unsigned g_leclip_wglog_cap, g_leclip_wglog_seq;
-__device__ __forceinline__ void wglog_end(const WgLog& w, unsigned tag, unsigned long long t0) {
+// c0: s_memtime (shader clock) taken next to t0: (c1 - c0) / (t1 - t0) x 100 MHz is the clock the CU held while the workgroup ran
+__device__ __forceinline__ void wglog_end(const WgLog& w, unsigned tag, unsigned long long t0, unsigned long long c0) {
     const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
     const unsigned long long i = atomicAdd(w.buf, 1ull);
     if (i < w.cap) {
-        unsigned long long* e = w.buf + 2 + 4 * i;
+        unsigned long long* e = w.buf + 2 + 6 * i;
         unsigned hw, xcc;   // where the workgroup ran: HW_ID (se / sh / cu fields) and XCC_ID
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
         e[0] = ((unsigned long long)tag << 32) | blockIdx.x; e[1] = t0; e[2] = t1;
         e[3] = w.seq | ((unsigned long long)(hw & 0xffff) << 32) | ((unsigned long long)(xcc & 0xf) << 48);
+        e[4] = c0; e[5] = c1;
     }
 }
 #endif

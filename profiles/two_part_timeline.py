@@ -46,7 +46,7 @@ def run(streams, steps=3):
         for _ in range(4):
             cc(img, if_test=True)
         torch.cuda.synchronize()
-        log = torch.zeros(2 + 4 * CAP, dtype=torch.int64, device=dev)
+        log = torch.zeros(2 + 6 * CAP, dtype=torch.int64, device=dev)
         setter(log.data_ptr(), CAP)
         for _ in range(steps):
             cc(img, if_test=True)
@@ -54,15 +54,16 @@ def run(streams, steps=3):
         setter(None, 0)
     raw = log.cpu().numpy().view(np.uint64)
     n = int(min(raw[0], CAP))
-    e = raw[2:2 + 4 * n].reshape(n, 4)
+    e = raw[2:2 + 6 * n].reshape(n, 6)
     tag, t0, t1 = (e[:, 0] >> np.uint64(32)).astype(np.int64), e[:, 1].astype(np.int64), e[:, 2].astype(np.int64)
     seq = (e[:, 3] & np.uint64(0xffffffff)).astype(np.int64)
     hw, xcc = ((e[:, 3] >> np.uint64(32)) & np.uint64(0xffff)).astype(np.int64), ((e[:, 3] >> np.uint64(48)) & np.uint64(0xf)).astype(np.int64)
+    clk = (e[:, 5] - e[:, 4]).astype(np.float64) / np.maximum((e[:, 2] - e[:, 1]).astype(np.float64), 1.0) * 0.1   # GHz: shader cycles per 10 ns
     cu = xcc * 1024 + ((hw >> 13) & 7) * 128 + ((hw >> 12) & 1) * 64 + ((hw >> 8) & 15)      # (xcc, se, sh, cu) -> one id per CU
     # the middle step: launches are numbered in host order; split the sequence numbers evenly over the steps
     per = int(seq.max()) // steps
     sel = (seq > per) & (seq <= 2 * per)
-    tag, t0, t1, seq, cu = tag[sel], t0[sel], t1[sel], seq[sel], cu[sel]
+    tag, t0, t1, seq, cu, clk = tag[sel], t0[sel], t1[sel], seq[sel], cu[sel], clk[sel]
     # per CU: the gap between one workgroup's end and the next one's begin
     gaps = []
     for c in np.unique(cu):
@@ -88,9 +89,10 @@ def run(streams, steps=3):
     for k in np.unique(tag):
         m = tag == k
         name = NAMES.get(int(k), f"gemm256 PF={(int(k) - 0x100) // 16} CFG={(int(k) - 0x100) % 16}")
-        kinds[name] = (len(np.unique(seq[m])), float((t1[m] - t0[m]).sum()) / 100.0 / N_CU)
-    for name, (nl, cu_t) in sorted(kinds.items()):
-        print(f"    {name:24s} {nl:3d} launches, {cu_t:8.1f} us of chip time")
+        kinds[name] = (len(np.unique(seq[m])), float((t1[m] - t0[m]).sum()) / 100.0 / N_CU, float(np.median(clk[m])), float(np.percentile(clk[m], 10)),
+                       float(np.percentile(clk[m], 90)))
+    for name, (nl, cu_t, c50, c10, c90) in sorted(kinds.items()):
+        print(f"    {name:24s} {nl:3d} launches, {cu_t:8.1f} us of chip time, shader clock while running: median {c50:.2f} GHz (p10 {c10:.2f}, p90 {c90:.2f})")
     return span
 
 
