@@ -461,6 +461,10 @@ def test_full_batch_properties(ops, dt):
         finally:
             eng.cls_last_block = True
     assert torch.equal(full, whole) and torch.equal(feats2, feats_whole)
+    # odd batch sizes through the same rules (129 -> parts of 65 + 64; 65 and 3 -> one part): still the rows of the full batch
+    with torch.no_grad():
+        for n in (129, 65, 3):
+            assert torch.equal(cc(img[256 - n:].contiguous(), if_test=True)[0], full[256 - n:])
 
 
 @pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 0.6)])
