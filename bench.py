@@ -29,10 +29,11 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+import leclip_amd  # noqa: E402
 # The image engine runs the two halves of a batch on two HIP streams, which only overlap when they sit on different hardware queues.  The
 # runtime has 4 by default and shares them among every stream in use (null stream, the two part streams, RCCL's): room for the rest.
-# Must be set before the HIP runtime starts; measured equal to the default on one GPU (profiles/r02_ab_stream_parts.txt).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# Must happen before the HIP runtime starts; measured equal to the default on one GPU (profiles/r02_ab_stream_parts.txt).
+leclip_amd.configure()
 
 PEAK_MFMA_TFLOPS = 2516.6
 PEAK_HBM_GBS = 8000.0
@@ -71,7 +72,11 @@ def main():
     ap.add_argument("--mode", default="score", choices=["score", "tune"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
+    ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no torchrun environment: print the launcher "
+                    "command this invocation would start (one JSON line) and exit without starting it")
     args = ap.parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)
     if args.mode == "tune":
         return tune(args)
 
@@ -86,7 +91,8 @@ def main():
 
     overrides = env_overrides()
     rank, world, local = parallel.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:   # only reachable under a launcher whose rank count differs from --gpus (a bare invocation self-launches)
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a HIP device"
     dev = torch.device("cuda", torch.cuda.current_device())
     arch = synth.ARCHS[args.arch]
@@ -225,10 +231,7 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"], result["mAP"], ref_pack = cpu_baseline(args, arch, sd, cc, ctx, dev)
-        if not (abs(result["mAP"]["hip"] - result["mAP"]["oracle_fp32"]) <= 0.2):
-            result["mAP"]["accuracy_gate"] = f"MISSED: |mAP - oracle| > 0.2 in {args.dtype}"
-        else:
-            result["mAP"]["accuracy_gate"] = "met (|mAP - oracle| <= 0.2)"
+        result["mAP"]["accuracy_gate"] = accuracy_gate(result["mAP"], args.dtype)
     else:
         ref_pack = None
     # Companion measurement: the engine's own default computes, in the LAST residual block, only what the class token needs (identical
@@ -253,12 +256,40 @@ def main():
         comp = {"value": B * args.steps / dt2, "unit": "img/s", "ms_per_step": dt2 / args.steps * 1e3, "steps": args.steps}
         if ref_pack is not None:
             comp["mAP"] = score_against(ref_pack, cc2, arch, dev)
+            comp["mAP"]["accuracy_gate"] = accuracy_gate(comp["mAP"], "bf16")
         result["bf16"] = comp
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def launcher_argv(n_gpus, bench_args, port):
+    """The command a bare ``python bench.py --gpus N ...`` turns into: one rank per GPU under torch.distributed.run on
+    127.0.0.1 (the container's hostname may not resolve), the same flags passed through."""
+    passed = [a for a in bench_args if a != "--dry-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + passed
+
+
+def self_launch(args):
+    """``--gpus N`` (N > 1) without a torchrun environment: start the N ranks as a CHILD process and exit with its code.  Nothing
+    here imports torch or touches a device - replacing a process that has initialised the GPU (exec) is forbidden on this pool, and a
+    child keeps the parent's stdout, so rank 0's JSON line is this invocation's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    argv = launcher_argv(args.gpus, sys.argv[1:], port)
+    if args.dry_launch:
+        print(json.dumps({"launch": argv}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it across processes)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.exit(subprocess.run(argv, env=env).returncode)
 
 
 def env_overrides():
@@ -285,7 +316,8 @@ def tune(args):
 
     overrides = env_overrides()
     rank, world, _ = parallel.init_from_env()
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE={world}")
     B = args.batch if args.batch != 256 else 512
     cfg = get_cfg_default()
     cfg.merge_from_list(["MODEL.BACKBONE.NAME", args.arch, "MODEL.BACKBONE.PATH", "synthetic:0:cond", "TRAINER.Caption.PREC",
@@ -383,10 +415,41 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
     base = {"value": n * cb / spent, "unit": "img/s", "cores": cores, "kind": "port",
             "sample": f"{n} batches of {cb} images, fp32 torch-CPU oracle forward + logits, {spent:.1f} s of CPU work, "
                       f"torch {torch.__version__}, {cores} threads"}
-    m = {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(labels, ref), "hip": mAP(labels, hip),
-         "max_abs_logit_diff": float(np.abs(ref - hip).max()),
-         "top1_agree": float((ref.argmax(1) == hip.argmax(1)).mean())}
+    m = {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(labels, ref), "hip": mAP(labels, hip)}
+    m.update(label_index_evidence(ref, hip))
     return base, m, {"ref": ref, "labels": labels, "n": n, "cb": cb}
+
+
+def label_index_evidence(ref, hip):
+    """Label-index agreement between the oracle's fp32 logits and the HIP logits, with the evidence for every image whose top-1
+    label differs: the oracle's own top-1 / top-2 margin and its margin to the label the HIP path picked, against the error band
+    2 x max |logit difference| - two logits closer than the band cannot be ordered by any arithmetic with that error, so a
+    disagreement inside it is a tie broken by rounding; one outside it would be a wrong result (north star: label-index outputs
+    bit-exact in the fp32 mode, where the band is ~3e-6 and no disagreement occurs)."""
+    import numpy as np
+    err = float(np.abs(ref - hip).max())
+    band = 2.0 * err
+    r1, h1 = ref.argmax(1), hip.argmax(1)
+    items = []
+    for i in np.nonzero(r1 != h1)[0]:
+        top2 = np.sort(ref[i])[-2:]
+        items.append({"image": int(i), "oracle_top1": int(r1[i]), "hip_top1": int(h1[i]),
+                      "oracle_top1_top2_margin": float(top2[1] - top2[0]),
+                      "oracle_margin_to_hip_pick": float(ref[i, r1[i]] - ref[i, h1[i]]),
+                      "inside_error_band": bool(top2[1] - top2[0] <= band)})
+    return {"max_abs_logit_diff": err, "top1_agree": float((r1 == h1).mean()), "error_band": band,
+            "logit_spread_std": float(ref.std(1).mean()), "top1_disagreements": items,
+            "top1_disagreements_all_inside_band": all(d["inside_error_band"] for d in items)}
+
+
+def accuracy_gate(m, dtype):
+    """North star: mAP within +-0.2 of the reference path, label indices exact up to ties inside the arithmetic's error band."""
+    missed = []
+    if not abs(m["hip"] - m["oracle_fp32"]) <= 0.2:
+        missed.append("|mAP - oracle| > 0.2")
+    if not m["top1_disagreements_all_inside_band"]:
+        missed.append("a top-1 disagreement lies outside the error band")
+    return f"MISSED in {dtype}: " + "; ".join(missed) if missed else "met (|mAP - oracle| <= 0.2; every top-1 disagreement is a tie inside the error band)"
 
 
 def score_against(pack, cc, arch, dev):
@@ -399,8 +462,9 @@ def score_against(pack, cc, arch, dev):
         hip = np.concatenate([cc(torch.from_numpy(synth.make_images(pack["cb"], arch.image_resolution, seed=4321, start=i * pack["cb"])).to(dev),
                                  if_test=True)[0].float().cpu().numpy() for i in range(pack["n"])])
     ref = pack["ref"]
-    return {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(pack["labels"], ref), "hip": mAP(pack["labels"], hip),
-            "max_abs_logit_diff": float(np.abs(ref - hip).max()), "top1_agree": float((ref.argmax(1) == hip.argmax(1)).mean())}
+    m = {"n_images": int(ref.shape[0]), "oracle_fp32": mAP(pack["labels"], ref), "hip": mAP(pack["labels"], hip)}
+    m.update(label_index_evidence(ref, hip))
+    return m
 
 
 if __name__ == "__main__":

@@ -53,7 +53,8 @@ int leclip_layernorm_fwd(const void* x, const float* gamma, const float* beta, v
 /* Y[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]       (nn.Linear weight layout, K contiguous)
  * Replaces the F.linear calls of clip/model.py:213-217,223,226-227 (MHA in-proj / out-proj, mlp.c_fc + QuickGELU
  * (model.py:202-204: x*sigmoid(1.702x)), mlp.c_proj) with the bias, activation and residual add fused.
- * A and W share ab_dtype (F32: exact-fp32 MFMA path; F16/BF16: 32x32x16 MFMA, fp32 accumulate).
+ * A and W share ab_dtype (F32: exact-fp32 MFMA path; F16/BF16: v_mfma_f32_16x16x32 in both kernel families, fp32 accumulate,
+ * ascending-K order per output element - an element's bits do not depend on M or on the family that computed it).
  * bias: fp32 or NULL.  residual: res_dtype or NULL; may alias Y (in-place residual stream).
  * Constraints: N % 128 == 0 and K % 64 == 0 (F16/BF16); N % 64 == 0 and K % 32 == 0 (F32). */
 int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias, const void* residual, void* Y,

@@ -12,6 +12,8 @@
 #include <string.h>
 #include <zlib.h>
 
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -71,7 +73,11 @@ struct Bpe {
     std::unordered_map<std::string, int> encoder;       // token -> id
     std::unordered_map<std::string, int> rank;          // "a\x01b" -> merge rank
     std::string byte_sym[256];                          // GPT-2 byte alphabet (UTF-8 of the mapped code point)
+    // word -> ids memo.  The handle is shared process-wide (clip.py keeps one) and ctypes drops the GIL during a call, so two
+    // Python threads (a threaded caption loader) may encode at once: lookups take the lock shared, inserts exclusive.  The
+    // other members are read-only after leclip_bpe_open.
     std::unordered_map<std::string, std::vector<int>> cache;
+    std::shared_mutex cache_mu;
     int sot, eot;
 };
 
@@ -103,8 +109,11 @@ bool read_gz(const char* path, std::string& out) {
 
 // greedy BPE on one pre-token (already mapped through the byte alphabet): ids appended to `ids`
 void bpe_word(Bpe& b, const std::vector<std::string>& syms_in, const std::string& key, std::vector<int>& ids) {
-    auto hit = b.cache.find(key);
-    if (hit != b.cache.end()) { ids.insert(ids.end(), hit->second.begin(), hit->second.end()); return; }
+    {
+        std::shared_lock<std::shared_mutex> rd(b.cache_mu);
+        auto hit = b.cache.find(key);
+        if (hit != b.cache.end()) { ids.insert(ids.end(), hit->second.begin(), hit->second.end()); return; }
+    }
     std::vector<std::string> parts = syms_in;
     parts.back() += "</w>";
     while (parts.size() > 1) {
@@ -127,7 +136,10 @@ void bpe_word(Bpe& b, const std::vector<std::string>& syms_in, const std::string
         auto e = b.encoder.find(p);
         out.push_back(e == b.encoder.end() ? -1 : e->second);
     }
-    b.cache[key] = out;
+    {
+        std::unique_lock<std::shared_mutex> wr(b.cache_mu);
+        b.cache.emplace(key, out);   // (a racing thread may have inserted the same word: identical value, emplace keeps the first)
+    }
     ids.insert(ids.end(), out.begin(), out.end());
 }
 

@@ -1,4 +1,4 @@
-// Shared device helpers for the gfx950 kernels (wave64, MFMA 32x32x16, fp32 accumulate).
+// Shared device helpers for the gfx950 kernels (wave64; GEMMs on v_mfma_f32_16x16x32, attention on 32x32x16; fp32 accumulate).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

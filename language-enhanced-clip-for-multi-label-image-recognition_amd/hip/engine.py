@@ -11,8 +11,12 @@ Data layout in HBM (all row-major, token-major within an image / prompt):
 * weights [N, K] (nn.Linear layout, K contiguous) in the compute dtype; biases, LayerNorm affine,
   class / positional embeddings, token table in fp32.
 
-One forward of a tower with L blocks is 1 + 7L + 1 kernel launches (patch-embed adds 2) on the
-caller's current HIP stream; nothing synchronises and all workspaces are cached per batch size.
+One forward of a tower with L blocks is 1 + 7L + 1 kernel launches (patch-embed adds 2).  The text tower and small image
+batches enqueue them on the caller's current HIP stream.  A large image batch (``VisionEngine.streams`` parts, B >= 128) runs
+as contiguous parts, EVERY part on an engine-owned side stream shared per device (never the caller's): the side streams wait for
+the caller's stream before the first launch (fork) and the caller's stream waits for them after the last (join), so to the
+caller the forward is ordered like any other work on its stream.  Nothing synchronises the host and all workspaces are cached
+per (batch size, stream).
 """
 from __future__ import annotations
 
@@ -218,6 +222,26 @@ def _part_streams(device, n: int):
     return pool[:n]
 
 
+_HWQ_NOTED = False
+
+
+def _note_hw_queues():
+    """Say once when the stream parts run without the hardware-queue setting in effect (leclip_amd.configure() not called before the
+    HIP runtime started and GPU_MAX_HW_QUEUES not set by the user): results are identical, but the parts may share a hardware queue and
+    then run one after the other (measured 22.2 k instead of 26 k img/s at GPU_MAX_HW_QUEUES=1)."""
+    global _HWQ_NOTED
+    if _HWQ_NOTED:
+        return
+    _HWQ_NOTED = True
+    import leclip_amd
+    state = leclip_amd.hw_queue_state()
+    if state in ("late", "default"):
+        import warnings
+        warnings.warn("leclip_amd: stream parts are running with the HIP runtime's default hardware queues (" + state + "); call "
+                      "leclip_amd.configure() before the first device call, or set GPU_MAX_HW_QUEUES=8, for the overlapped schedule",
+                      RuntimeWarning, stacklevel=3)
+
+
 class VisionEngine:
     """VisionTransformer.forward (clip/model.py:259-276) as a HIP kernel sequence."""
 
@@ -243,7 +267,8 @@ class VisionEngine:
         self.proj_t = self.proj.t().contiguous()   # [E, d]: K-contiguous B operand of the tail kernel's projection
         self.blocks = pack_blocks(visual.transformer.resblocks, dtype, device)
         self._ws: Dict[int, tuple] = {}
-        # Large batches run as `streams` contiguous parts on HIP streams of their own (the first on the caller's): every big GEMM
+        # Large batches run as `streams` contiguous parts, every part on a per-device shared side stream forked from and joined to the
+        # caller's stream (_on_streams; none of the parts runs on the caller's stream itself): every big GEMM
         # is a persistent grid of one workgroup per CU whose last round of tiles leaves most CUs idle (ViT-B/16, B=256: out-proj
         # and c_proj are 2.31 rounds), and the other part's kernels fill those CUs.  Images are independent and every kernel
         # is batch-invariant bit for bit, so the split does not change a single output value (tests/test_gpu_parity.py).
@@ -270,6 +295,7 @@ class VisionEngine:
             return fn(image)
         cur = torch.cuda.current_stream(self.device)
         side = _part_streams(self.device, len(bounds))
+        _note_hw_queues()
         for st in side:
             st.wait_stream(cur)                      # fork BEFORE any part is enqueued: the inputs are ready on the caller's stream
         outs = []

@@ -288,9 +288,11 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, ln_partials: Optional[torch.Tensor] = None, ln_stats_ws: Optional[torch.Tensor] = None,
             eps: float = 1e-5) -> torch.Tensor:
     """GEMM with LayerNorm folded around it (leclip_gemm_ln_partials_fwd).  The A-side LayerNorm statistics come either as
-    ``ln_stats`` [M,2] (mean, rstd) or as the producer's block partials ``ln_partials`` [M, K/64, 2] (merged inside the GEMM
-    on the 256x256 kernel, through ``ln_stats_ws`` [M,2] otherwise); ``stats_out`` [M, N/64, 2] receives the output rows'
-    block partials (sum, M2 about the block mean) for the next LayerNorm."""
+    ``ln_stats`` [M,2] (mean, rstd) or as the producer's block partials ``ln_partials`` [M, K/64, 2]; the C entry point then ALWAYS
+    launches the separate merge kernel (ln_stats_finalize_kernel, same stream, in front of the GEMM) that turns the partials into
+    (mean, rstd) in ``ln_stats_ws`` [M,2], which the caller provides - an in-kernel merge was built twice and rejected for register
+    spills.  ``stats_out`` [M, N/64, 2] receives the output rows' block partials (sum, M2 about the block
+    mean) for the next LayerNorm."""
     m, k, lda = _rows2d(a, "a")
     n, kw, ldw = _rows2d(w, "w")
     if k != kw or a.dtype != w.dtype:

@@ -478,8 +478,10 @@ class Caption_distill_double:
         return last
 
     def before_train(self):
-        """dassl/engine/trainer.py:375-388: resume from OUTPUT_DIR when RESUME is set."""
-        directory = self.cfg.get("RESUME", "") or ""
+        """dassl/engine/trainer.py:409-413: ALWAYS look for a checkpoint to continue from - in OUTPUT_DIR, or in RESUME when that is
+        set (RESUME only overrides the directory) - so a restarted job with the same OUTPUT_DIR continues instead of overwriting
+        its checkpoints from epoch 0."""
+        directory = self.cfg.get("RESUME", "") or self.output_dir or ""
         if directory:
             self.start_epoch = self.resume_model_if_exist(directory)
         self.time_start = time.time()

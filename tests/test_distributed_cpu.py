@@ -156,3 +156,24 @@ def test_resume_restores_optimizer_and_scheduler(tmp_path):
     b2 = tr2.optim.state_dict()["state"][0]["momentum_buffer"]
     assert torch.equal(b1, b2) and tr2.optim.param_groups[0]["lr"] == lr_saved and tr2.sched.last_epoch == tr.sched.last_epoch
     assert build_trainer(_trainer_cfg()).resume_model_if_exist(str(tmp_path / "nothing_here")) == 0
+
+
+def test_restart_into_the_same_output_dir_continues(tmp_path):
+    """dassl/engine/trainer.py:409-413: before_train always looks for a checkpoint in OUTPUT_DIR (RESUME only overrides the
+    directory), so a job restarted with the same OUTPUT_DIR continues from the saved epoch instead of overwriting it from 0."""
+    from leclip_amd.registry import build_trainer
+    cfg = _trainer_cfg()
+    cfg.OUTPUT_DIR = str(tmp_path / "run")
+    tr = build_trainer(cfg)
+    tr.before_train()
+    assert tr.start_epoch == 0                      # nothing there yet: from scratch
+    tr.save_model(0, tr.output_dir)
+    tr2 = build_trainer(cfg)
+    tr2.before_train()
+    assert tr2.start_epoch == 1 and torch.equal(tr2.model_default.prompt_learner.ctx, tr.model_default.prompt_learner.ctx)
+    other = _trainer_cfg()
+    other.OUTPUT_DIR = str(tmp_path / "elsewhere")
+    other.RESUME = str(tmp_path / "run")           # RESUME overrides where to look
+    tr3 = build_trainer(other)
+    tr3.before_train()
+    assert tr3.start_epoch == 1

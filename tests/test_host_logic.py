@@ -316,6 +316,21 @@ def test_native_bpe_matches_python_tokenizer(tmp_path):
     for row, t in zip(got, short):
         ids = [sot] + py.encode(t) + [eot]
         assert row[:len(ids)].tolist() == ids and int(row[len(ids):].abs().sum()) == 0
+    # one handle shared by threads (ctypes drops the GIL inside the call): the word memo is locked, results equal the sequential ones
+    import threading
+    fresh = clipmod.NativeTokenizer(str(path))     # empty memo: the threads race on first inserts of the same words
+    pool = [t for t in texts if "&" not in t]
+    want = [py.encode(t) for t in pool]
+    got_thr = [None] * 6
+    def work(k):
+        got_thr[k] = [fresh.encode(t) for t in (pool if k % 2 == 0 else pool[::-1])]
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    for k in range(6):
+        assert got_thr[k] == (want if k % 2 == 0 else want[::-1])
     long_text = " ".join(["photo"] * 100)
     with pytest.raises(RuntimeError):
         nat.tokenize([long_text], 77)
@@ -359,3 +374,51 @@ def test_stream_part_rule():
     assert stream_parts(5, 2, [5, 0], 128, **vb) is None
     with pytest.raises(ValueError):
         stream_parts(256, 2, [100, 100], 128, **vb)
+
+
+def test_bench_self_launches_multi_gpu_runs():
+    """A bare `python bench.py --gpus N` (the driver's invocation) must start its own ranks: --dry-launch prints the launcher command."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    for mode in ("score", "tune"):
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode,
+                              "--dry-launch"], env=env, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        argv = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+        assert argv[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=2" in argv and "--nnodes=1" in argv
+        assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and int(argv[argv.index("--master-port") + 1]) > 0
+        tail = argv[argv.index(os.path.join(root, "bench.py")) + 1:]
+        assert tail == ["--gpus", "2", "--steps", "3", "--warmup", "1", "--mode", mode]       # flags pass through, --dry-launch does not
+    # under a launcher (RANK set) the same flags do not launch again: the process goes on to the device check
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.launcher_argv(8, ["--gpus", "8", "--dry-launch"], 29511)[-2:] == ["--gpus", "8"]
+
+
+def test_bench_label_index_evidence():
+    """bench.py's accuracy gate: a top-1 disagreement counts as a tie only when the oracle's own top-1 / top-2 margin is inside
+    twice the largest logit error; one outside it fails the gate."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    ref = np.array([[1.0, 0.999, 0.0], [2.0, 1.0, 0.0], [0.5, 0.1, 0.4]], dtype=np.float32)
+    hip = ref.copy()
+    hip[0] = [0.9990, 0.9995, 0.0]                       # near tie flips: margin 1e-3 <= band
+    ev = bench.label_index_evidence(ref, hip)
+    assert ev["top1_agree"] == pytest.approx(2 / 3) and len(ev["top1_disagreements"]) == 1
+    d = ev["top1_disagreements"][0]
+    assert d["image"] == 0 and d["oracle_top1"] == 0 and d["hip_top1"] == 1 and d["inside_error_band"]
+    assert d["oracle_top1_top2_margin"] == pytest.approx(1e-3, rel=1e-3) and ev["top1_disagreements_all_inside_band"]
+    assert bench.accuracy_gate(dict(ev, hip=50.0, oracle_fp32=50.1), "fp16").startswith("met")
+    assert bench.accuracy_gate(dict(ev, hip=50.0, oracle_fp32=50.3), "fp16").startswith("MISSED")
+    ev2 = dict(ev, top1_disagreements_all_inside_band=False)
+    assert "outside the error band" in bench.accuracy_gate(dict(ev2, hip=50.0, oracle_fp32=50.0), "fp16")
+    same = bench.label_index_evidence(ref, ref)
+    assert same["top1_agree"] == 1.0 and same["top1_disagreements"] == [] and same["top1_disagreements_all_inside_band"]
