@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 6
+#define LECLIP_ABI_VERSION 7
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -221,6 +221,19 @@ int leclip_l2norm_rows_fwd(float* x, int64_t rows, int dim, int64_t ld, void* st
  * scale * s * (max_c s + 1), s <- s * w, prob = softmax over positions of scale * e.  All fp32; out [B, C]. */
 int leclip_local_pool_fwd(const float* sim, float* out, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset,
                           float spatial_scale, float logit_scale, void* stream);
+/* The same pooling for the caption-as-image TRAINING branch (trainers/Caption_distill_double.py:473-513): the positions are the 77
+ * token positions of a caption run through the text tower (`if_sequence=True`, :474) and `text_mask = (captions == 0) * -10000`
+ * (:491) is added to both panels before anything else (:497-498, :505-506).  mask_tokens [B][mask_stride] int64 are the caption's
+ * token ids (position p of image b is masked where the id is 0), or NULL for no mask. */
+int leclip_local_pool_masked_fwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, float* out, int64_t B, int P, int C,
+                                 int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale, float logit_scale, void* stream);
+/* Gradient of that pooling w.r.t. the similarity panels (the `ranking_loss(output_local, ...)` term of :806-808 on its way to
+ * ctx_double / ctx_evidence): dout [B, C] -> dneg [B*P, C] (d / d s) and, with evidence, devi [B*P, C] (d / d e), contiguous.
+ * torch's max(-1) in the winner-take-all weight (:509) hands its gradient to the arg-max class; so does this.  The panels of one
+ * image must fit LDS (P * C * 12 bytes with evidence): the training branch pools 77 positions. */
+int leclip_local_pool_bwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, const float* dout, float* dneg, float* devi,
+                          int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale,
+                          float logit_scale, void* stream);
 
 /* ---- score post-processing of the reference's test loop
  * Sliding-window aggregation, trainers/Caption_distill_double.py:654-660: window_logits [B, W, C] are the scores of the W

@@ -73,6 +73,10 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 }
 
 #define PIN() __builtin_amdgcn_sched_barrier(0)
+// s_waitcnt lgkmcnt(0) as the compiler's own instruction (vmcnt 63, expcnt 7, lgkmcnt 0): unlike an asm statement it updates the
+// waitcnt pass's scoreboard, so no conservative lgkmcnt(0) is inserted later in front of the first use of a register that an LDS
+// read of the PREVIOUS block filled - which, behind a freshly issued read of the next block, would expose that read's latency.
+#define LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)
 
 // Timing / ablation hooks (skip the epilogue, the stores or the K-loop; start-up stagger; no cross-tile pipelining; strict
 // waits; grid cap; forced generic epilogue) exist only in the diagnostic library (make diag: -DLECLIP_DIAG, loaded by
@@ -196,11 +200,17 @@ struct PP {
         v8 (&b)[4] = (SEL & 2) ? bf2 : bfr;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
+#ifndef LECLIP_FR_MFMA_FIRST
             op(m);
             PIN();
+#endif
             const int i = m >> 2, j = m & 3;
             if (!PPDBG(16)) acc[rh][i][j] = SWAP ? mfma16(b[j], a[i], acc[rh][i][j]) : mfma16(a[i], b[j], acc[rh][i][j]);
             PIN();
+#ifdef LECLIP_FR_MFMA_FIRST
+            op(m);
+            PIN();
+#endif
         }
     }
     __device__ __forceinline__ void read_a1(int stage, int kh, int rh, int i, v8 (&dst)[4]) {
@@ -222,7 +232,7 @@ struct PP {
         for (int i = 0; i < 4; ++i) read_a1(0, 0, 0, i, af);
 #pragma unroll
         for (int j = 0; j < 4; ++j) read_b1(0, 0, j, bfr);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LGKM0();
     }
     // One K-tile = halves (t, 0) and (t, 1).  V = 0: halves n+4 of this tile exist; 1 = second to last K-tile; 2 = last.
     // X, nx, next_src: as for the ping-pong form below (stores of the previous epilogue younger than the prologue pieces;
@@ -235,7 +245,7 @@ struct PP {
         const int k2 = (t + 2) * TK;
         // ---- half (t, 0).  P0: fragments af / bfr; reads A(k0, r1) -> af2
         mma16<0>(0, [&](int m) { if (m < 4) read_a1(s, 0, 1, m, af2); });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LGKM0();
         if (V <= 1 || nx) {
             if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -254,10 +264,10 @@ struct PP {
             else if (m < 8) read_b1(s, 1, m - 4, bf2);
             else if (d0 && !(m & 1)) dma1(m < 12, s, 0, kd0, (m >> 1) & 1);   // m = 8, 10: B pieces; 12, 14: A pieces
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LGKM0();
         // ---- half (t, 1).  P0: fragments af / bf2; reads A(k1, r1) -> af2
         mma16<2>(0, [&](int m) { if (m < 4) read_a1(s, 1, 1, m, af2); });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LGKM0();
         if (V == 0 || (V == 1 && nx)) {
             if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
             else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -278,7 +288,7 @@ struct PP {
             }
             if (m >= 8 && d1 && !(m & 1)) dma1(m < 12, s, 1, kd1, (m >> 1) & 1);
         });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        LGKM0();
     }
 #endif
 

@@ -311,50 +311,169 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
     for (int k = lane * 4; k < dim; k += 256) { f32x4 t = *(const f32x4*)(xr + k); t[0] *= inv; t[1] *= inv; t[2] *= inv; t[3] *= inv; *(f32x4*)(xr + k) = t; }
 }
 
-// Local (dense) branch pooling, trainers/Caption_distill_double.py:447-462 with patches in place of the ResNet's HxW positions:
-//   s[p, c]  = <patch feature p, "negative" prompt c> (both normalised), e[p, c] the same against the evidence prompts
+// Local (dense) branch pooling, trainers/Caption_distill_double.py:447-462 (image branch: patches in place of the ResNet's HxW
+// positions) and :493-513 (caption-as-image training branch: the 77 token positions, `text_mask` added to both panels):
+//   s[p, c]  = <position feature p, "negative" prompt c> (both normalised) + bias[p], e[p, c] the same against the evidence prompts,
+//              bias[p] = -10000 where the caption's token id is 0 (:491, :497-498, :505-506), else 0
 //   evidence: w = softmax_c(tmp * s * (max_c s + 1));  s <- s * w;  prob = softmax_p(tmp * e)      (winner-take-all)
 //   else:     prob = softmax_p(tmp * s)
 //   logits_local[c] = sum_p logit_scale * s[p, c] * prob[p, c]
-// One workgroup per image; its [P, C] similarity panel(s) live in LDS.
-__global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict__ sim, float* __restrict__ out, int P, int C, int64_t ld,
-                                                         int64_t image_stride, int evi_off, float tmp, float logit_scale) {
-    extern __shared__ float sm[];      // s [P][C] (| e [P][C])
-    const int tid = threadIdx.x;
+// One workgroup per image.  The classes are processed CT at a time (the softmax over p is independent per class; the
+// winner-take-all row softmax needs only a per-position scale k, maximum and denominator, taken in a first pass straight
+// from global memory), so the LDS footprint is P * CT * 8 bytes whatever P and C are (ViT-L/14@336: P = 576).
+__global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict__ sim, const int64_t* __restrict__ mask_tok, float* __restrict__ out,
+                                                         int P, int C, int CT, int64_t ld, int64_t image_stride, int64_t mask_stride, int evi_off,
+                                                         float tmp, float logit_scale) {
+    extern __shared__ float sm[];      // k[P] | zmax[P] | den[P] | bias[P] | s [P][CT] (| e [P][CT])
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = sim + (int64_t)blockIdx.x * image_stride;
-    float* s = sm;
-    float* e = sm + P * C;
-    for (int i = tid; i < P * C; i += 256) {
-        const int p = i / C, c = i - p * C;
-        s[i] = src[(int64_t)p * ld + c];
-        if (evi_off >= 0) e[i] = src[(int64_t)p * ld + evi_off + c];
-    }
+    float *rk = sm, *rz = sm + P, *rd = sm + 2 * P, *bias = sm + 3 * P, *s = sm + 4 * P, *e = s + P * CT;
+    for (int p = tid; p < P; p += 256) bias[p] = (mask_tok && mask_tok[(int64_t)blockIdx.x * mask_stride + p] == 0) ? -10000.0f : 0.0f;
     __syncthreads();
     if (evi_off >= 0) {
-        for (int p = tid; p < P; p += 256) {     // per patch: softmax over classes of tmp * s * (max + 1), then s *= w
-            float* row = s + p * C;
-            float mx = row[0];
-            for (int c = 1; c < C; ++c) mx = fmaxf(mx, row[c]);
+        for (int p = wave; p < P; p += 4) {      // per position: scale, maximum and denominator of softmax_c(tmp * s * (max + 1))
+            const float* row = src + (int64_t)p * ld;
+            const float b = bias[p];
+            float mx = -INFINITY;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c] + b);
+            mx = wave_max(mx);
             const float k = tmp * (mx + 1.0f);
-            float zmax = k * row[0];
-            for (int c = 1; c < C; ++c) zmax = fmaxf(zmax, k * row[c]);
+            float zmax = -INFINITY;
+            for (int c = lane; c < C; c += 64) zmax = fmaxf(zmax, k * (row[c] + b));
+            zmax = wave_max(zmax);
             float den = 0.f;
-            for (int c = 0; c < C; ++c) den += expf(k * row[c] - zmax);
-            for (int c = 0; c < C; ++c) row[c] *= expf(k * row[c] - zmax) / den;
+            for (int c = lane; c < C; c += 64) den += expf(k * (row[c] + b) - zmax);
+            den = wave_sum(den);
+            if (lane == 0) { rk[p] = k; rz[p] = zmax; rd[p] = den; }
         }
         __syncthreads();
     }
-    const float* z = evi_off >= 0 ? e : s;
-    for (int c = tid; c < C; c += 256) {         // per class: softmax over patches, weighted sum
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        const int ct = C - c0 < CT ? C - c0 : CT;
+        for (int i = tid; i < P * ct; i += 256) {
+            const int p = i / ct, c = i - p * ct;
+            const float v = src[(int64_t)p * ld + c0 + c] + bias[p];
+            if (evi_off >= 0) {
+                s[p * CT + c] = v * (expf(rk[p] * v - rz[p]) / rd[p]);
+                e[p * CT + c] = src[(int64_t)p * ld + evi_off + c0 + c] + bias[p];
+            } else {
+                s[p * CT + c] = v;
+            }
+        }
+        __syncthreads();
+        const float* z = evi_off >= 0 ? e : s;
+        for (int c = tid; c < ct; c += 256) {    // per class: softmax over positions, weighted sum
+            float mx = tmp * z[c];
+            for (int p = 1; p < P; ++p) mx = fmaxf(mx, tmp * z[p * CT + c]);
+            float den = 0.f, num = 0.f;
+            for (int p = 0; p < P; ++p) {
+                const float w = expf(tmp * z[p * CT + c] - mx);
+                den += w;
+                num = fmaf(w, s[p * CT + c], num);
+            }
+            out[(int64_t)blockIdx.x * C + c0 + c] = logit_scale * num / den;
+        }
+        __syncthreads();
+    }
+}
+
+// Backward of the pooling w.r.t. both similarity panels (prompt tuning through the local branch, reference :806-808: the ranking loss
+// on `output_local`).  dneg / devi [B*P, C] contiguous: d loss / d s, d loss / d e (before the bias, which is a constant).
+//   no evidence:  m[c] = sum_p s prob;                 ds[p,c] = dout[c] scale prob[p,c] (1 + tmp (s[p,c] - m[c]))
+//   evidence:     s' = s w, m[c] = sum_p s' prob;      de[p,c] = dout[c] scale tmp prob (s' - m[c]);   g = dout[c] scale prob   (= d/d s')
+//                 per position, with H = sum_c g s w, u_c = w_c (g_c s_c - H):  ds_c = g_c w_c + k u_c + [c == argmax_c s] tmp sum_c' u_c' s_c'
+//                 (k = tmp (max_c s + 1) depends on s through its maximum: torch's max(-1) hands that gradient to the arg-max element)
+// One workgroup per image, whole panels in LDS (positions x classes x 12 bytes: the caption branch is 77 x 80).
+__global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __restrict__ sim, const int64_t* __restrict__ mask_tok, const float* __restrict__ dout,
+                                                             float* __restrict__ dneg, float* __restrict__ devi, int P, int C, int64_t ld,
+                                                             int64_t image_stride, int64_t mask_stride, int evi_off, float tmp, float logit_scale) {
+    extern __shared__ float sm[];      // k[P] | zmax[P] | den[P] | bias[P] | amax[P] | cmx[C] | cden[C] | cm[C] | s [P][C] | g [P][C] (| e [P][C])
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = sim + (int64_t)blockIdx.x * image_stride;
+    float *rk = sm, *rz = sm + P, *rd = sm + 2 * P, *bias = sm + 3 * P;
+    int* ramax = (int*)(sm + 4 * P);
+    float *cmx = sm + 5 * P, *cden = cmx + C, *cm = cden + C, *s = cm + C, *g = s + P * C, *e = g + P * C;
+    const bool evi = evi_off >= 0;
+    for (int p = tid; p < P; p += 256) bias[p] = (mask_tok && mask_tok[(int64_t)blockIdx.x * mask_stride + p] == 0) ? -10000.0f : 0.0f;
+    __syncthreads();
+    for (int i = tid; i < P * C; i += 256) {
+        const int p = i / C, c = i - p * C;
+        s[i] = src[(int64_t)p * ld + c] + bias[p];
+        if (evi) e[i] = src[(int64_t)p * ld + evi_off + c] + bias[p];
+    }
+    __syncthreads();
+    if (evi) {
+        for (int p = wave; p < P; p += 4) {
+            const float* row = s + p * C;
+            float mx = -INFINITY;
+            int am = 0x7fffffff;
+            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c]);
+            mx = wave_max(mx);
+            for (int c = lane; c < C; c += 64) if (row[c] == mx) am = c < am ? c : am;     // first maximum
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(am, o); am = t < am ? t : am; }
+            const float k = tmp * (mx + 1.0f);
+            float zmax = -INFINITY;
+            for (int c = lane; c < C; c += 64) zmax = fmaxf(zmax, k * row[c]);
+            zmax = wave_max(zmax);
+            float den = 0.f;
+            for (int c = lane; c < C; c += 64) den += expf(k * row[c] - zmax);
+            den = wave_sum(den);
+            if (lane == 0) { rk[p] = k; rz[p] = zmax; rd[p] = den; ramax[p] = am; }
+        }
+        __syncthreads();
+    }
+    const float* z = evi ? e : s;
+    for (int c = tid; c < C; c += 256) {         // per class: softmax over positions; m[c] = sum_p s' prob
         float mx = tmp * z[c];
         for (int p = 1; p < P; ++p) mx = fmaxf(mx, tmp * z[p * C + c]);
         float den = 0.f, num = 0.f;
         for (int p = 0; p < P; ++p) {
             const float w = expf(tmp * z[p * C + c] - mx);
+            float sv = s[p * C + c];
+            if (evi) sv *= expf(rk[p] * sv - rz[p]) / rd[p];
             den += w;
-            num = fmaf(w, s[p * C + c], num);
+            num = fmaf(w, sv, num);
         }
-        out[(int64_t)blockIdx.x * C + c] = logit_scale * num / den;
+        cmx[c] = mx; cden[c] = den; cm[c] = num / den;
+    }
+    __syncthreads();
+    const float* dob = dout + (int64_t)blockIdx.x * C;
+    float* dn = dneg + (int64_t)blockIdx.x * P * C;
+    float* de = devi ? devi + (int64_t)blockIdx.x * P * C : nullptr;
+    for (int i = tid; i < P * C; i += 256) {
+        const int p = i / C, c = i - p * C;
+        const float prob = expf(tmp * z[i] - cmx[c]) / cden[c];
+        const float gs = dob[c] * logit_scale * prob;
+        if (!evi) {
+            dn[i] = gs * (1.0f + tmp * (s[i] - cm[c]));
+        } else {
+            const float sv = s[i] * (expf(rk[p] * s[i] - rz[p]) / rd[p]);
+            de[i] = gs * tmp * (sv - cm[c]);
+            g[i] = gs;
+        }
+    }
+    if (!evi) return;
+    __syncthreads();
+    for (int p = wave; p < P; p += 4) {          // through s' = s * softmax_c(k s), k = tmp (max_c s + 1)
+        const float* row = s + p * C;
+        const float* gr = g + p * C;
+        const float k = rk[p], zm = rz[p], dnm = rd[p];
+        float H = 0.f;
+        for (int c = lane; c < C; c += 64) H = fmaf(gr[c] * row[c], expf(k * row[c] - zm) / dnm, H);
+        H = wave_sum(H);
+        float S = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float w = expf(k * row[c] - zm) / dnm;
+            S = fmaf(w * (gr[c] * row[c] - H), row[c], S);
+        }
+        S = wave_sum(S);
+        const int am = ramax[p];
+        for (int c = lane; c < C; c += 64) {
+            const float w = expf(k * row[c] - zm) / dnm;
+            const float u = w * (gr[c] * row[c] - H);
+            dn[p * C + c] = fmaf(k, u, gr[c] * w) + (c == am ? tmp * S : 0.0f);
+        }
     }
 }
 
@@ -443,17 +562,49 @@ extern "C" int leclip_l2norm_rows_fwd(float* x, int64_t rows, int dim, int64_t l
     return leclip_check_launch("l2norm_rows_kernel");
 }
 
+static int local_pool_args_ok(const float* sim, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, const int64_t* mask_tokens,
+                              int64_t mask_stride) {
+    return sim && B > 0 && P > 0 && C > 0 && ld >= C && image_stride >= (int64_t)(P - 1) * ld + C && !(evidence_offset >= 0 && evidence_offset + C > ld) &&
+           !(mask_tokens && mask_stride < P);
+}
+
 extern "C" int leclip_local_pool_fwd(const float* sim, float* out, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset,
                                      float spatial_scale, float logit_scale, void* stream) {
-    if (!sim || !out || B <= 0 || P <= 0 || C <= 0 || ld < C || image_stride < (int64_t)(P - 1) * ld + C || (evidence_offset >= 0 && evidence_offset + C > ld)) {
+    return leclip_local_pool_masked_fwd(sim, nullptr, 0, out, B, P, C, ld, image_stride, evidence_offset, spatial_scale, logit_scale, stream);
+}
+
+extern "C" int leclip_local_pool_masked_fwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, float* out, int64_t B, int P, int C,
+                                            int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale, float logit_scale, void* stream) {
+    if (!out || !local_pool_args_ok(sim, B, P, C, ld, image_stride, evidence_offset, mask_tokens, mask_stride)) {
         leclip_set_error("local_pool: null pointer or inconsistent sizes");
         return LECLIP_E_INVALID;
     }
-    const size_t lds = (size_t)P * C * 4 * (evidence_offset >= 0 ? 2 : 1);
-    if (lds > 160 * 1024) { leclip_set_error("local_pool: P=%d x C=%d does not fit LDS", P, C); return LECLIP_E_UNSUPPORTED; }
+    // classes per pass: as many as fit 144 KiB beside the four per-position vectors (>= 1 for P <= 4000)
+    const int panels = evidence_offset >= 0 ? 2 : 1;
+    const int64_t budget = 144 * 1024 - 16 * (int64_t)P;
+    int ct = budget > 0 ? (int)(budget / ((int64_t)P * 4 * panels)) : 0;
+    if (ct < 1) { leclip_set_error("local_pool: P=%d positions do not fit LDS", P); return LECLIP_E_UNSUPPORTED; }
+    if (ct > C) ct = C;
+    const size_t lds = (size_t)P * 16 + (size_t)P * ct * 4 * panels;
     static bool attr_set[LECLIP_MAX_DEVICES] = {};
     leclip_set_max_lds(local_pool_kernel, 160 * 1024, attr_set);
-    hipLaunchKernelGGL(local_pool_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, sim, out, P, C, ld, image_stride, evidence_offset,
-                       spatial_scale, logit_scale);
+    hipLaunchKernelGGL(local_pool_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, sim, mask_tokens, out, P, C, ct, ld, image_stride, mask_stride,
+                       evidence_offset, spatial_scale, logit_scale);
     return leclip_check_launch("local_pool_kernel");
+}
+
+extern "C" int leclip_local_pool_bwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, const float* dout, float* dneg, float* devi,
+                                     int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale, float logit_scale,
+                                     void* stream) {
+    if (!dout || !dneg || (evidence_offset >= 0) != (devi != nullptr) || !local_pool_args_ok(sim, B, P, C, ld, image_stride, evidence_offset, mask_tokens, mask_stride)) {
+        leclip_set_error("local_pool_bwd: null pointer or inconsistent sizes");
+        return LECLIP_E_INVALID;
+    }
+    const size_t lds = ((size_t)5 * P + 3 * C + (size_t)P * C * (evidence_offset >= 0 ? 3 : 2)) * 4;
+    if (lds > 160 * 1024) { leclip_set_error("local_pool_bwd: P=%d x C=%d panels do not fit LDS (the training branch pools 77 token positions)", P, C); return LECLIP_E_UNSUPPORTED; }
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(local_pool_bwd_kernel, 160 * 1024, attr_set);
+    hipLaunchKernelGGL(local_pool_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, sim, mask_tokens, dout, dneg, devi, P, C, ld, image_stride,
+                       mask_stride, evidence_offset, spatial_scale, logit_scale);
+    return leclip_check_launch("local_pool_bwd_kernel");
 }

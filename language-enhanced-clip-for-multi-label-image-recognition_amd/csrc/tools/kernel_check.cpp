@@ -146,9 +146,10 @@ static void bench() {
     const int64_t M = 256 * 197;
     struct S { int N, K, act; bool res; const char* name; } shapes[] = {
         {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
-    const bool quick = getenv("LECLIP_BENCH_QUICK") != nullptr;
+    const char* only = getenv("LECLIP_BENCH_DT");   // "f16" / "bf16": GEMM shapes of that dtype only (A/B scripts)
+    const bool quick = getenv("LECLIP_BENCH_QUICK") != nullptr || only != nullptr;
     for (int dt : {LECLIP_BF16, LECLIP_F16}) for (auto& s : shapes) {
-        if (quick && dt != LECLIP_BF16) continue;
+        if (only ? strcmp(only, dtn(dt)) != 0 : (quick && dt != LECLIP_BF16)) continue;
         auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
         auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
         Buf dA(Ap.size()), dW(Wp.size()), dB(s.N * 4), dR(Rp.size()), dY((size_t)M * s.N * 2);

@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 PACKAGE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libleclip_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU = 0, 1
@@ -76,6 +76,9 @@ SIGNATURES = {
     "leclip_scatter_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "leclip_l2norm_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "leclip_local_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
+    "leclip_local_pool_masked_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
+    "leclip_local_pool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float,
+                                      c_void_p]),
     "leclip_bpe_open": (c_void_p, [c_char_p]),
     "leclip_bpe_close": (None, [c_void_p]),
     "leclip_bpe_vocab_size": (c_int64, [c_void_p]),

@@ -109,3 +109,52 @@ class CosineLogitsFunction(torch.autograd.Function):
     def backward(ctx, dlogits: torch.Tensor):
         img, txt = ctx.saved_tensors
         return None, ops.l2norm_logits_bwd(img, txt, dlogits.float().contiguous(), ctx.scale), None
+
+
+class LocalPoolFunction(torch.autograd.Function):
+    """logits_local of the caption-as-image training branch (CDD.py:493-513): normalise the sequence features and the "negative"
+    (and evidence) prompt features, similarity panels on the exact-fp32 MFMA GEMM, ``text_mask``, spatial softmax over the 77
+    positions (winner-take-all weighting with evidence prompts), weighted sum.  Backward w.r.t. the two sets of text features: the
+    pooling's own backward kernel (leclip_local_pool_bwd), then - per panel - the cosine-similarity backward already used for the
+    global logits (leclip_l2norm_logits_bwd with the 77 positions of every caption as its "images").  The sequence features come
+    from the frozen text tower: no gradient."""
+
+    @staticmethod
+    def forward(ctx, seq: torch.Tensor, txt_neg: torch.Tensor, txt_evi, tokens: torch.Tensor, spatial_scale: float, logit_scale: float):
+        b, t, e = seq.shape
+        flat = seq.detach().float().contiguous().view(b * t, e)
+        tn = txt_neg.detach().float().contiguous()
+        te = txt_evi.detach().float().contiguous() if txt_evi is not None else None
+        sim, c_pad = local_similarity(flat, tn, te)
+        c = tn.shape[0]
+        evi = c_pad if te is not None else -1
+        toks = tokens.to(device=seq.device, dtype=torch.int64).contiguous()
+        out = ops.local_pool(sim, b, t, 0, c, evi, spatial_scale, logit_scale, mask_tokens=toks)
+        ctx.save_for_backward(flat, tn, te if te is not None else tn, sim, toks)
+        ctx.meta = (b, t, c, evi, float(spatial_scale), float(logit_scale), te is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout: torch.Tensor):
+        flat, tn, te, sim, toks = ctx.saved_tensors
+        b, t, c, evi, spatial_scale, logit_scale, has_evi = ctx.meta
+        dneg, devi = ops.local_pool_bwd(sim, dout.float().contiguous(), b, t, 0, c, evi, spatial_scale, logit_scale, mask_tokens=toks)
+        d_tn = ops.l2norm_logits_bwd(flat, tn, dneg, 1.0)
+        d_te = ops.l2norm_logits_bwd(flat, te, devi, 1.0) if has_evi else None
+        return None, d_tn, d_te, None, None, None
+
+
+def local_similarity(flat: torch.Tensor, txt_neg: torch.Tensor, txt_evi=None):
+    """[rows, c_pad (x2)] fp32 cosine similarities of every (unnormalised) feature row against the negative (| evidence) prompt
+    features: rows and prompts normalised by the row-norm kernel, contraction on the exact-fp32 MFMA GEMM; the prompt panel is
+    zero-padded to 64-row blocks (the GEMM's N granularity).  Returns (sim, c_pad)."""
+    rows = [ops.l2norm_rows_(txt_neg.clone())]
+    if txt_evi is not None:
+        rows.append(ops.l2norm_rows_(txt_evi.clone()))
+    c = rows[0].shape[0]
+    cp = (c + 63) // 64 * 64
+    w = torch.zeros((cp * len(rows), rows[0].shape[1]), dtype=torch.float32, device=flat.device)
+    for i, r in enumerate(rows):
+        w[i * cp:i * cp + c] = r
+    fhat = ops.l2norm_rows_(flat.clone())
+    return ops.gemm(fhat, w, out_dtype=torch.float32), cp

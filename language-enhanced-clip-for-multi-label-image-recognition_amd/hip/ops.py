@@ -509,13 +509,42 @@ def l2norm_rows_(x: torch.Tensor) -> torch.Tensor:
 
 
 def local_pool(sim: torch.Tensor, batch: int, tokens: int, first: int, n_cls: int, evidence_offset: int, spatial_scale: float,
-               logit_scale: float) -> torch.Tensor:
-    """sim [batch * tokens, ld] fp32 (positions ``first`` .. tokens-1 of every image are pooled) -> logits_local [batch, n_cls]."""
+               logit_scale: float, mask_tokens: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sim [batch * tokens, ld] fp32 (positions ``first`` .. tokens-1 of every image are pooled) -> logits_local [batch, n_cls].
+    ``mask_tokens`` [batch, tokens] int64 (caption-as-image branch): positions whose token id is 0 get the reference's -10000."""
     _dev(sim, "sim")
     assert sim.dtype == torch.float32 and sim.is_contiguous() and sim.shape[0] == batch * tokens
     ld = sim.shape[1]
     out = torch.empty((batch, n_cls), dtype=torch.float32, device=sim.device)
     view = sim[first:]          # skip the class-token row of image 0; image stride stays tokens * ld
-    _capi.check(_capi.load().leclip_local_pool_fwd(_ptr(view), _ptr(out), batch, tokens - first, n_cls, ld, tokens * ld, evidence_offset,
-                                                   float(spatial_scale), float(logit_scale), _stream()), "local_pool")
+    mask = _mask_arg(mask_tokens, batch, tokens, first, sim.device)
+    _capi.check(_capi.load().leclip_local_pool_masked_fwd(_ptr(view), _ptr(mask), tokens, _ptr(out), batch, tokens - first, n_cls, ld, tokens * ld,
+                                                          evidence_offset, float(spatial_scale), float(logit_scale), _stream()), "local_pool")
     return out
+
+
+def _mask_arg(mask_tokens, batch, tokens, first, device):
+    if mask_tokens is None:
+        return None
+    _dev(mask_tokens, "mask_tokens")
+    if mask_tokens.dtype != torch.int64 or not mask_tokens.is_contiguous() or mask_tokens.shape != (batch, tokens) or mask_tokens.device != device:
+        raise TypeError("local_pool: mask_tokens must be a contiguous int64 [batch, tokens] tensor on the similarity panel's device")
+    return mask_tokens.view(-1)[first:]
+
+
+def local_pool_bwd(sim: torch.Tensor, dout: torch.Tensor, batch: int, tokens: int, first: int, n_cls: int, evidence_offset: int,
+                   spatial_scale: float, logit_scale: float, mask_tokens: Optional[torch.Tensor] = None):
+    """Gradient of ``local_pool`` w.r.t. the two similarity panels: (dneg, devi or None), each [batch * (tokens - first), n_cls] fp32."""
+    _dev(sim, "sim")
+    _dev(dout, "dout")
+    assert sim.dtype == torch.float32 and sim.is_contiguous() and sim.shape[0] == batch * tokens
+    if dout.dtype != torch.float32 or not dout.is_contiguous() or dout.shape != (batch, n_cls):
+        raise TypeError("local_pool_bwd: dout must be contiguous float32 [batch, n_cls]")
+    ld = sim.shape[1]
+    p = tokens - first
+    dneg = torch.empty((batch * p, n_cls), dtype=torch.float32, device=sim.device)
+    devi = torch.empty_like(dneg) if evidence_offset >= 0 else None
+    mask = _mask_arg(mask_tokens, batch, tokens, first, sim.device)
+    _capi.check(_capi.load().leclip_local_pool_bwd(_ptr(sim[first:]), _ptr(mask), tokens, _ptr(dout), _ptr(dneg), _ptr(devi), batch, p, n_cls, ld, tokens * ld,
+                                                   evidence_offset, float(spatial_scale), float(logit_scale), _stream()), "local_pool_bwd")
+    return dneg, devi

@@ -11,7 +11,9 @@ engines.  Attribute names equal the reference's because they are also the checkp
   start as copies of the initial context.
 * ``class_token_position`` "middle"/"front" build only ``prompts`` in the reference and then fail at the return
   (:262-308); only "end" is accepted here.
-* ``DenseCLIP`` (:354-559) needs the ResNet ``attnpool`` and is outside the north-star scope.
+* ``DenseCLIP`` (:354-559): the image side of its test branch is defined for the ResNet ``attnpool`` only; the ViT analogue used
+  here is stated in the class docstring.  Its caption-as-image training branch (:473-541) involves no image tower and is built as
+  written.
 """
 from __future__ import annotations
 
@@ -253,7 +255,8 @@ class DenseCLIP(CustomCLIP):
     prompts, spatial softmax over positions at ``TRAIN.spatial_SCALE_image`` (or ``spatial_T.exp()``), optionally the
     evidence prompts' winner-take-all weighting (``TRAINER.Caption.use_evidence``), ``logits_local = sum_p scale * s * prob``.
     The top-k caption-feature mixing of :437-440 needs the reference's ChatGLM caption-feature file and is not part of it.
-    Inference only (``if_test=True``); returns (logits_, logits_local, None, None, None) like the reference's test branch."""
+    ``if_test=True`` returns (logits_, logits_local, None, None, None) like the reference's test branch; ``if_test=False`` is the
+    reference's caption-as-image TRAINING branch (:473-541, ``_forward_captions``), which needs no image tower at all."""
 
     def __init__(self, cfg, classnames, clip_model, return_interm_layers=False, nctx=None):
         super().__init__(cfg, classnames, clip_model)
@@ -286,7 +289,7 @@ class DenseCLIP(CustomCLIP):
     def forward(self, image=None, captions=None, if_test: bool = False, model_name: str = "ema"):
         from ..hip import ops
         if not if_test:
-            raise NotImplementedError("DenseCLIP for a ViT is an inference-time branch in this build (if_test=True); tune with CustomCLIP")
+            return self._forward_captions(captions)
         with torch.no_grad():
             f = self._prompt_features()
             dense = self.image_encoder.dense_features(image)                 # [B, T, E] fp32
@@ -299,6 +302,62 @@ class DenseCLIP(CustomCLIP):
             evi = f["c_pad"] if "text_features_evidence" in f else -1
             logits_local = ops.local_pool(sim, b, t, 1, f["text_features"].shape[0], evi, tmp, logit_scale)
         return logits_, logits_local, None, None, None
+
+    def _text_features_of(self, learner, with_grad: bool):
+        """(text_features, text_features_neg, text_features_evidence or None) of one prompt learner: the two or three prompt sets go
+        through the text tower as ONE batch of 160 / 240 prompts (one kernel sequence instead of three; with_grad: one backward)."""
+        prompts, prompts_double, prompts_evidence, _, _, _ = learner()
+        use_evi = bool(self.cfg.TRAINER.Caption.get("use_evidence", False))
+        sets = [prompts, prompts_double] + ([prompts_evidence] if use_evi else [])
+        toks = self.tokenized_prompts.to(prompts.device)
+        n = prompts.shape[0]
+        if with_grad:
+            feats = self.text_encoder(torch.cat(sets, dim=0), torch.cat([toks] * len(sets), dim=0))
+        else:
+            with torch.no_grad():
+                feats = self.text_encoder(torch.cat([p.detach() for p in sets], dim=0), torch.cat([toks] * len(sets), dim=0))
+        return feats[:n], feats[n:2 * n], (feats[2 * n:] if use_evi else None)
+
+    def _forward_captions(self, captions):
+        """The reference's texts-as-images TRAINING branch (:473-541): a caption's 77 token positions through the frozen text tower are
+        its "image" - the EOT row the global feature (:476), all rows the local ones (:477) - scored against the three learnable prompt
+        sets: logits_ = scale * cos(global, ctx prompts) (:494), logits_local = spatial pooling of cos(positions, ctx_double prompts)
+        under `text_mask`, with the ctx_evidence prompts' winner-take-all weighting when use_evidence (:495-513), and - TRAIN.ema - the
+        same two scores from the momentum copy of the prompt learner, without gradient (:515-539).
+        -> (logits_, logits_local, image_features [L, B, E] normalised, text_features normalised, logits_m_, logits_local_m)."""
+        from ..hip import ops
+        from ..hip.autograd import CosineLogitsFunction, LocalPoolFunction
+        cfg = self.cfg
+        if captions is None:
+            raise ValueError("DenseCLIP.forward(if_test=False) takes tokenised captions [B, 77] (the reference's model(None, captions))")
+        if cfg.TRAIN.IF_LEARN_SCALE or cfg.TRAIN.IF_LEARN_spatial_SCALE:
+            # no shipped config learns them (train_caption.py:114-115, every configs/trainers/*.yaml): the gradient to temperature /
+            # spatial_T is not formed here
+            raise NotImplementedError("TRAIN.IF_LEARN_SCALE / IF_LEARN_spatial_SCALE: learnable scales are not supported in the tuning step")
+        logit_scale, tmp = 4.0, float(cfg.TRAIN.spatial_SCALE_text)
+        captions = captions.to(self.prompt_learner.ctx.device).long().contiguous()
+        with torch.no_grad():   # the caption encoder is the frozen text tower (:762-765)
+            seq = self.text_encoder(captions, None, if_embedding=False, if_sequence=True).float().contiguous()     # [B, L, E]
+            b, l, e = seq.shape
+            _, eot_flat = ops.eot_index(captions)
+            image_feature_ = ops.gather_rows(seq.view(b * l, e), eot_flat)                                          # :476
+        training = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
+        text_features, text_features_neg, text_features_evi = self._text_features_of(self.prompt_learner, training)
+        self._text_cache = None
+        self.prompt_text_features = None
+        logits_ = CosineLogitsFunction.apply(image_feature_, text_features, logit_scale)
+        logits_local = LocalPoolFunction.apply(seq, text_features_neg, text_features_evi, captions, tmp, logit_scale)
+        logits_m_, logits_local_m = None, None
+        if self.ema:
+            with torch.no_grad():
+                self._momentum_update()
+                tf_m, tfn_m, tfe_m = self._text_features_of(self.prompt_learner_m, False)
+                logits_m_ = ops.l2norm_logits(image_feature_, tf_m.float().contiguous(), logit_scale)
+                logits_local_m = LocalPoolFunction.apply(seq, tfn_m, tfe_m, captions, tmp, logit_scale)
+        with torch.no_grad():
+            image_features = ops.l2norm_rows_(seq.view(b * l, e).clone()).view(b, l, e).permute(1, 0, 2)
+            text_features_n = ops.l2norm_rows_(text_features.detach().float().clone())
+        return logits_, logits_local, image_features, text_features_n, logits_m_, logits_local_m
 
 
 @TRAINER_REGISTRY.register()
@@ -552,15 +611,38 @@ class Caption_distill_double:
         optim = self._optims[name]
         model.train()
         inp, label = self.parse_batch_train(batch)
-        if inp.dtype in (torch.int64, torch.int32):
-            output = model(None, inp.long())[0]
+        output_local = output_m = output_local_m = None
+        if isinstance(model, DenseCLIP):
+            # the reference's step as shipped (TRAIN.MODEL = "DenseCLIP", train_caption.py:110): `model(None, captions)` (:802)
+            if inp.dtype not in (torch.int64, torch.int32):
+                raise TypeError("DenseCLIP is tuned on tokenised captions [B, 77] (texts as images); image batches tune CustomCLIP")
+            output, output_local, _, _, output_m, output_local_m = model(None, inp.long())
+        elif inp.dtype in (torch.int64, torch.int32):
+            res = model(None, inp.long())
+            output, output_m = res[0], res[3]
         else:
-            output = model(inp, None)[0]
+            res = model(inp, None)
+            output, output_m = res[0], res[3]
         lf = self.cfg.TRAIN.LOSSFUNC
+        summary = {}
         if lf == "double_ranking":
+            # :806-815: ranking loss on the global and - when the model has one - the local head; with the momentum copy's scores the
+            # distillation term kl(log_softmax(output) || softmax(output_m)) + 10000 * kl(local || local_m), batchmean
             loss = ranking_loss(output, label, scale_=1.0, margin_=1)
+            if output_local is not None:
+                loss = loss + ranking_loss(output_local, label, scale_=1.0, margin_=1)
+            if output_m is not None:
+                kl = torch.nn.KLDivLoss(reduction="batchmean")
+                logp = torch.nn.functional.log_softmax
+                ema_loss = kl(logp(output, dim=-1), torch.softmax(output_m, dim=-1))
+                if output_local is not None and output_local_m is not None:
+                    ema_loss = ema_loss + kl(logp(output_local, dim=-1), torch.softmax(output_local_m, dim=-1)) * 10000
+                summary = {"r_loss": loss.item(), "ema_loss": ema_loss.item()}
+                loss = loss + ema_loss
         elif lf == "bce":
             loss = norm_logits_BCEloss(output, label.float())
+            if output_local is not None:
+                loss = loss + norm_logits_BCEloss(output_local, label.float())
         else:
             raise NotImplementedError(f"loss function {lf} not implemented")
         if not torch.isfinite(loss):
@@ -570,7 +652,10 @@ class Caption_distill_double:
         self._allreduce_grads([p for g in optim.param_groups for p in g["params"]])
         optim.step()
         model._text_cache = None
-        return {f"loss_{lf}": loss.item(), "loss": loss.item()}
+        if not summary:
+            summary = {f"loss_{lf}": loss.item()}
+        summary["loss"] = loss.item()
+        return summary
 
     # ------------------------------------------------------------------------------------------------------- testing
     def cooccurrence_matrix(self):

@@ -248,6 +248,49 @@ def dense_clip_forward(image: Tensor, sd: Dict[str, Tensor], ctx: Tensor, ctx_do
     return logits_, local_pool(logits_neg, logits_evi, tmp_scale, scale)
 
 
+def dense_clip_forward_captions(captions: Tensor, sd: Dict[str, Tensor], ctx: Tensor, ctx_double: Tensor, ctx_evidence: Optional[Tensor],
+                                prefix: Tensor, suffix: Tensor, tokenized_prompts: Tensor, tmp_scale: float = 50.0, scale: float = 4.0):
+    """DenseCLIP.forward(captions=..., if_test=False), Caption_distill_double.py:473-513 (fixed scales: IF_LEARN_SCALE and
+    IF_LEARN_spatial_SCALE are False in every shipped config): (logits_, logits_local).  Differentiable w.r.t. the three contexts
+    (torch autograd is the gradient oracle of the tuning step).  Pinned: make_golden.py executes those reference lines on the
+    reference's own TextEncoder (tests/golden/caption_branch.npz)."""
+    image_feat = text_encoder(captions, None, sd, if_embedding=False, if_sequence=True)                  # :474  [B, L, E]
+    image_feature_ = image_feat[torch.arange(image_feat.shape[0]), captions.argmax(dim=-1)]             # :476
+    image_features = image_feat.permute(1, 0, 2)                                                         # :477  [L, B, E]
+    enc = lambda c: l2_normalize(text_encoder(prompt_learner_forward(c, prefix, suffix), tokenized_prompts, sd))
+    text_features, text_features_neg = enc(ctx), enc(ctx_double)                                          # :480-488
+    image_feature_ = l2_normalize(image_feature_)
+    image_features = l2_normalize(image_features)
+    text_mask = (captions == 0).long() * (-10000)                                                         # :491  [B, L]
+    logits_ = scale * image_feature_ @ text_features.t()                                                  # :494
+    logits_neg = image_features @ text_features_neg.t()                                                   # :495  [L, B, C]
+    logits_neg = (logits_neg.permute(2, 1, 0) + text_mask[None, :, :]).permute(2, 1, 0)                  # :496-497
+    logits_evi = None
+    if ctx_evidence is not None:                                                                          # :500-509
+        logits_evi = image_features @ enc(ctx_evidence).t()
+        logits_evi = (logits_evi.permute(2, 1, 0) + text_mask[None, :, :]).permute(2, 1, 0)
+    return logits_, local_pool(logits_neg, logits_evi, tmp_scale, scale)
+
+
+def double_ranking_loss(output: Tensor, output_local: Optional[Tensor], label: Tensor, output_m: Optional[Tensor] = None,
+                        output_local_m: Optional[Tensor] = None) -> Tensor:
+    """forward_backward's LOSSFUNC == 'double_ranking' branch, Caption_distill_double.py:805-815 with trainers/utils.py:85-93
+    (ranking_loss, scale_ = 1, margin_ = 1): both heads, plus - with the momentum copy's scores - the distillation term."""
+    def rank(y_pred, y_true):
+        y_true_ = y_true.float()
+        tmp = 1 - y_pred[:, None, :] + y_pred[:, :, None]
+        part = torch.maximum(torch.zeros_like(tmp), tmp) * y_true_[:, None, :] * (1 - y_true_[:, :, None])
+        return part.sum(dim=-1).sum(dim=-1).mean()
+    loss = rank(output, label)
+    if output_local is not None:
+        loss = loss + rank(output_local, label)
+    if output_m is not None:
+        kl = torch.nn.KLDivLoss(reduction="batchmean")
+        loss = loss + kl(F.log_softmax(output, dim=-1), F.softmax(output_m, dim=-1)) \
+            + kl(F.log_softmax(output_local, dim=-1), F.softmax(output_local_m, dim=-1)) * 10000
+    return loss
+
+
 def flatten_taps(taps: dict, prefix: str = "") -> Dict[str, np.ndarray]:
     out = {}
     for k, v in taps.items():

@@ -101,6 +101,79 @@ def main():
                         extra_texts=np.array(extra_texts), tokens_extra=tok_extra)
     print("tokens:", tok_photo[0, :10], tok_ctx[0, :22])
 
+    # Multi-script fixture for the tokenizers (Python and native C++): ~240 seeded strings over Latin (with diacritics),
+    # Greek, Cyrillic, CJK, Arabic, Hebrew, Devanagari, Thai, digits of several scripts, punctuation runs, contractions, emoji
+    # and every kind of whitespace, tokenised by the REFERENCE's SimpleTokenizer.encode (no SOT / EOT; ragged -> padded with
+    # -1 and a length vector).  No '&' (html.unescape is exercised by extra_texts above) and none of the two code points whose
+    # lower-casing is context dependent (U+03A3, U+017F): those are the inputs the native tokenizer hands back to Python.
+    import random
+    rnd = random.Random(20261004)
+    pools = {
+        "latin": ["photo", "of", "a", "Person", "BICYCLE", "traffic", "light", "naïve", "café", "Ångström", "über", "façade", "jalapeño",
+                  "don't", "it's", "we'll", "they've", "I'd", "you're", "I'm", "rock'n'roll", "co-operate", "e-mail", "state-of-the-art"],
+        "greek": ["φωτογραφία", "ενός", "σκύλου", "αβγ", "ΔΕΛΤΑ", "ποδήλατο", "γάτα"],
+        "cyrillic": ["фотография", "собаки", "Велосипед", "КОШКА", "поезд", "ёлка", "їжак"],
+        "cjk": ["一张", "狗的", "照片", "自転車", "ねこ", "イヌ", "사진", "고양이", "中文", "世界"],
+        "arabic": ["صورة", "كلب", "دراجة", "قطة"],
+        "hebrew": ["תמונה", "של", "כלב", "חתול"],
+        "indic": ["कुत्ते", "की", "तस्वीर", "साइकिल", "பூனை"],
+        "thai": ["รูปภาพ", "ของ", "สุนัข", "แมว"],
+        "digits": ["0", "7", "12", "2023", "3.14", "1,000", "٣٤٥", "१२३", "๔๕", "½", "²", "Ⅷ", "①"],
+        "punct": [".", ",", "!", "?", "...", "!!", "?!", ";", ":", "-", "--", "—", "(", ")", "[", "]", "\"", "'", "''", "#", "$", "%", "*", "+", "/", "=", "@", "^", "_", "~", "€", "£", "¥", "©", "®", "™", "°", "«", "»", "¿", "¡"],
+        "emoji": ["🐶", "🐱", "🚲", "🚦", "👍🏽", "❤️", "😀", "👨‍👩‍👧"],
+        "space": [" ", "  ", "\t", "\n", "\r\n", "\u00a0", "\u2003", "\u3000", " \t "],
+    }
+    kinds = list(pools)
+    multi = []
+    while len(multi) < 240:
+        n_parts = rnd.randint(1, 9)
+        parts = []
+        for _ in range(n_parts):
+            kind = rnd.choice(kinds) if rnd.random() < 0.7 else "latin"
+            w = rnd.choice(pools[kind])
+            r = rnd.random()
+            if kind == "latin" and r < 0.2:
+                w = w.upper()
+            parts.append(w)
+            parts.append(rnd.choice(pools["space"]) if rnd.random() < 0.8 else "")
+        text = "".join(parts)
+        if rnd.random() < 0.15:
+            text = rnd.choice(pools["space"]) + text
+        if "&" in text or "\u03a3" in text or "\u017f" in text or not text.strip():
+            continue
+        multi.append(text)
+    multi_ids = [tokenizer.encode(t) for t in multi]
+    width = max(len(v) for v in multi_ids)
+    multi_arr = np.full((len(multi), width), -1, dtype=np.int64)
+    for i, v in enumerate(multi_ids):
+        multi_arr[i, :len(v)] = v
+    # every key of the offline prompt cache (clip/prompt_cache.json: what clip.tokenize answers from when no merge table is
+    # installed, e.g. on the GPU box), tokenised by the reference tokenizer
+    import json
+    with open(os.path.join(ROOT, "language-enhanced-clip-for-multi-label-image-recognition_amd", "clip", "prompt_cache.json")) as f:
+        cache_keys = sorted(json.load(f))
+    cache_ids = [tokenizer.encode(k) for k in cache_keys]
+    cwidth = max(len(v) for v in cache_ids)
+    cache_arr = np.full((len(cache_keys), cwidth), -1, dtype=np.int64)
+    for i, v in enumerate(cache_ids):
+        cache_arr[i, :len(v)] = v
+    np.savez_compressed(os.path.join(OUT, "tokens_multiscript.npz"), texts=np.array(multi), ids=multi_arr,
+                        lengths=np.array([len(v) for v in multi_ids], dtype=np.int64),
+                        cache_keys=np.array(cache_keys), cache_ids=cache_arr,
+                        cache_lengths=np.array([len(v) for v in cache_ids], dtype=np.int64))
+    print("multi-script token fixture:", len(multi), "strings, longest", width, "ids;", len(cache_keys), "prompt-cache keys")
+    if "--tokens-only" in sys.argv:
+        return 0
+    if "--caption-branch-only" in sys.argv:
+        def build_ref(arch, seed, dist):
+            sd = synth.make_state_dict(arch, seed=seed, dist=dist)
+            m = ref_model.CLIP(arch.embed_dim, arch.image_resolution, arch.vision_layers, arch.vision_width, arch.vision_patch_size,
+                               arch.context_length, arch.vocab_size, arch.transformer_width, arch.transformer_heads, arch.transformer_layers)
+            m.load_state_dict(sd, strict=True)
+            return m.float().eval(), sd
+        caption_branch_goldens(np, torch, synth, build_ref, tokenizer, tokenize, classnames)
+        return 0
+
     # ------------------------------------------------------------------ helpers
     def build_ref(arch, seed, dist):
         sd = synth.make_state_dict(arch, seed=seed, dist=dist)
@@ -244,6 +317,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "metrics_kat.npz"), **kat)
     postprocess_goldens(np, torch, rng)
     multicrop_goldens(np, torch)
+    caption_branch_goldens(np, torch, synth, build_ref, tokenizer, tokenize, classnames)
     print("wrote", sorted(os.listdir(OUT)))
     return 0
 
@@ -326,6 +400,107 @@ def postprocess_goldens(np, torch, rng):
         out[f"n4.logits_local.{tag}"] = ns4["logits_local"].numpy()
     np.savez_compressed(os.path.join(OUT, "postprocess.npz"), **out)
     print("postprocess: s_ag", out["n2.s_ag"].shape, "adjusted", out["n3.output_pos_adjusted"].shape)
+
+
+def caption_branch_goldens(np, torch, synth, build_ref, tokenizer, tokenize, classnames):
+    """SURVEY 8f N1, the step every shipped config trains (TRAIN.MODEL = "DenseCLIP"): DenseCLIP.forward(None, captions) and the
+    double_ranking (+ EMA distillation) loss, with gradients w.r.t. ctx / ctx_double / ctx_evidence from torch autograd THROUGH THE
+    REFERENCE'S OWN CODE.  The trainer module is not importable (mmcv, yacs, torchvision, a module-level .cuda()), so its source is
+    executed here as text slices: the classes TextEncoder (:72-101) and PromptLearner (:104-308) whole, the training branch of
+    DenseCLIP.forward (:473-541), _momentum_update (:555-559) and the loss lines (:806-815), on the reference's model.py CLIP with
+    the tiny synthetic weights, the reference tokenizer and trainers/utils.py's ranking_loss.  Outputs - data only - are the fixture."""
+    import copy
+    import textwrap
+    import torch.nn as nn
+    import torch.nn.functional as F
+    cdd = open(os.path.join(REF, "trainers", "Caption_distill_double.py")).read()
+    np.deprecate = getattr(np, "deprecate", lambda f=None, **k: (f if f is not None else (lambda g: g)))   # (removed in numpy 2)
+    tu = _load("ref_tutils2", os.path.join(REF, "trainers", "utils.py"))
+
+    def clip_tokenize(texts, context_length=77, truncate=False):
+        return torch.from_numpy(tokenize([texts] if isinstance(texts, str) else list(texts), context_length, truncate))
+    ns = {"torch": torch, "nn": nn, "F": F, "clip": types.SimpleNamespace(tokenize=clip_tokenize), "_tokenizer": tokenizer}
+    exec(_dedent_slice(cdd, "class TextEncoder(nn.Module):", "class PromptLearner(nn.Module):"), ns)
+    exec(_dedent_slice(cdd, "class PromptLearner(nn.Module):", "class CustomCLIP(nn.Module):"), ns)
+    fwd_src = _dedent_slice(cdd, "image_feat = self.text_encoder(captions, None, if_embedding=False, if_sequence=True)",
+                            "logits_m_, logits_local_m = None, None", True)
+    mom_src = _dedent_slice(cdd, "def _momentum_update(self):", "# kl_loss = nn.KLDivLoss(reduction=\"batchmean\")\n# ce_loss = torch.nn.CrossEntropyLoss()\n\n@TRAINER_REGISTRY")
+    loss_src = _dedent_slice(cdd, "r_loss = ranking_loss(output, label, scale_ = 1.0, margin_ = 1)", "                    loss = r_loss\n", True)
+    ns_m = {"torch": torch}
+    exec(mom_src, ns_m)
+
+    arch = synth.TINY
+    m, _sd = build_ref(arch, seed=1, dist="cond")
+    torch.set_grad_enabled(True)
+    for prm in m.parameters():
+        prm.requires_grad_(False)
+    sentences = ["a photo of a person and a dog.", "a cat sits on a couch next to a remote", "two bicycles and a traffic light",
+                 "a pizza on a dining table with a fork, a knife and a cup", "an airplane", "a bird, a boat and a kite over a bench by the sea"]
+    captions = clip_tokenize(sentences, truncate=True)
+    names = [c.replace("_", " ") for c in classnames]
+    label = torch.zeros(len(sentences), len(names))
+    for i, sent in enumerate(sentences):
+        for j, nme in enumerate(names):
+            if nme in sent:
+                label[i, j] = 1.0
+    out = {"captions": captions.numpy(), "label": label.numpy(), "arch": np.array("tiny"), "weights": np.array("seed=1 dist=cond"),
+           "spatial_SCALE_text": np.float64(50.0), "momentum": np.float64(0.995)}
+    for tag, use_evidence, ema in (("plain", False, False), ("evidence_ema", True, True)):
+        class _Cfg:
+            class INPUT:
+                SIZE = (arch.image_resolution, arch.image_resolution)
+            class TRAINER:
+                class Caption:
+                    N_CTX, CTX_INIT, CSC, CLASS_TOKEN_POSITION = 16, "", False, "end"
+            class TRAIN:
+                IF_LEARN_SCALE, IF_LEARN_spatial_SCALE, spatial_SCALE_text, momentum = False, False, 50, 0.995
+        _Cfg.TRAINER.Caption.use_evidence = use_evidence
+        _Cfg.TRAIN.ema = ema
+        import contextlib, io
+        with contextlib.redirect_stdout(io.StringIO()):      # (the class prints its initialisation banner)
+            pl = ns["PromptLearner"](_Cfg, classnames, m)
+        width = arch.transformer_width
+        with torch.no_grad():
+            pl.ctx.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=0)))
+            pl.ctx_double.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=1)))
+            pl.ctx_evidence.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=2)))
+        pl_m = copy.deepcopy(pl)
+        with torch.no_grad():      # a momentum copy that has drifted from the live prompts (as after some training)
+            pl_m.ctx.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=10)))
+            pl_m.ctx_double.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=11)))
+            pl_m.ctx_evidence.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=12)))
+            for prm in pl_m.parameters():
+                prm.requires_grad = False
+        stub = types.SimpleNamespace(text_encoder=ns["TextEncoder"](m), prompt_learner=pl, prompt_learner_m=pl_m,
+                                     tokenized_prompts=pl.tokenized_prompts, cfg=_Cfg, model_pairs=[[pl, pl_m]])
+        stub._momentum_update = lambda st=stub: ns_m["_momentum_update"](st)
+        out[f"{tag}.m_ctx_before"] = pl_m.ctx.detach().numpy().copy()
+        out[f"{tag}.m_ctx_double_before"] = pl_m.ctx_double.detach().numpy().copy()
+        out[f"{tag}.m_ctx_evidence_before"] = pl_m.ctx_evidence.detach().numpy().copy()
+        ns_f = {"torch": torch, "self": stub, "captions": captions}
+        exec(fwd_src, ns_f)
+        output, output_local, output_m, output_local_m = ns_f["logits_"], ns_f["logits_local"], ns_f["logits_m_"], ns_f["logits_local_m"]
+        out[f"{tag}.logits"] = output.detach().numpy().copy()
+        out[f"{tag}.logits_local"] = output_local.detach().numpy().copy()
+        if ema:
+            out[f"{tag}.logits_m"] = output_m.detach().numpy().copy()
+            out[f"{tag}.logits_local_m"] = output_local_m.detach().numpy().copy()
+            out[f"{tag}.m_ctx_after"] = pl_m.ctx.detach().numpy().copy()
+        ns_l = {"torch": torch, "F": F, "ranking_loss": tu.ranking_loss, "kl_loss": nn.KLDivLoss(reduction="batchmean"),    # (:792)
+                "output": output, "output_local": output_local, "output_m": output_m, "output_local_m": output_local_m, "label": label}
+        exec(loss_src, ns_l)
+        loss = ns_l["loss"]
+        loss.backward()
+        out[f"{tag}.loss"] = np.float64(loss.item())
+        out[f"{tag}.r_loss"] = np.float64(ns_l["r_loss"].item())
+        out[f"{tag}.grad_ctx"] = pl.ctx.grad.numpy().copy()
+        out[f"{tag}.grad_ctx_double"] = pl.ctx_double.grad.numpy().copy()
+        out[f"{tag}.grad_ctx_evidence"] = (pl.ctx_evidence.grad.numpy().copy() if pl.ctx_evidence.grad is not None
+                                           else np.zeros((16, width), dtype=np.float32))
+        print("caption branch", tag, "loss", float(loss), "|g ctx|", float(pl.ctx.grad.abs().max()), "|g double|", float(pl.ctx_double.grad.abs().max()),
+              "|g evi|", float(np.abs(out[f"{tag}.grad_ctx_evidence"]).max()))
+    torch.set_grad_enabled(False)
+    np.savez_compressed(os.path.join(OUT, "caption_branch.npz"), **out)
 
 
 def multicrop_goldens(np, torch):

@@ -12,6 +12,6 @@ done
 for round in 1 2 3; do
   for v in "$@"; do
     exe=$L/exp/kernel_check_$v; [ "$v" = base ] && exe=$L/leclip_kernel_check
-    echo "== $v round $round"; timeout -k 10 120 $exe bench 2>&1 | grep "bench gemm" | grep f16 | grep -v bf16 || exit 1
+    echo "== $v round $round"; LECLIP_BENCH_DT=f16 timeout -k 10 120 $exe bench 2>&1 | grep "bench gemm" || exit 1
   done
 done

@@ -361,3 +361,154 @@ def test_trainer_test_with_multi_scale_windows(ops, golden_dir, tmp_path):
     assert abs(got - want) < 1e-9 and 0.0 < got <= 100.0
     plain = tr.test(mode="train")          # mode != "test": no window aggregation (reference :637)
     assert plain != got
+
+
+# ------------------------------------------------------------------------ DenseCLIP caption-as-image training branch (N1)
+@pytest.mark.parametrize("evidence", [False, True])
+@pytest.mark.parametrize("masked", [False, True])
+def test_local_pool_masked_fwd_bwd(ops, evidence, masked):
+    """leclip_local_pool_masked_fwd / leclip_local_pool_bwd against torch autograd through the oracle's restatement of :493-513
+    (softmax over the positions, text_mask, winner-take-all weighting with its max(-1) gradient)."""
+    from oracle import clip_oracle as co
+    b, p, c, cp = 5, 77, 80, 128
+    sim = np.tanh(synth.normal(3, "sim", (b * p, 2 * cp), std=0.6)).astype(np.float32) * 0.5
+    toks = (synth.uniform(4, "tok", (b, p), 0, 1) * 400).astype(np.int64) + 1
+    if masked:
+        for i in range(b):
+            toks[i, 9 + 7 * i:] = 0
+    sim_t, tok_t = torch.from_numpy(sim), torch.from_numpy(toks)
+    neg = sim_t.view(b, p, 2 * cp)[:, :, :c].permute(1, 0, 2).double().requires_grad_(True)          # [P, B, C]
+    evi = sim_t.view(b, p, 2 * cp)[:, :, cp:cp + c].permute(1, 0, 2).double().requires_grad_(True)
+    bias = ((tok_t == 0).long() * (-10000)).double().t()[:, :, None] if masked else 0.0
+    ref = co.local_pool(neg + bias, (evi + bias) if evidence else None, 50.0, 4.0)
+    dout = torch.from_numpy(synth.normal(5, "dout", (b, c)))
+    ref.backward(dout.double())
+    evi_off = cp if evidence else -1
+    mask = tok_t.to(DEV) if masked else None
+    got = ops.local_pool(sim_t.to(DEV), b, p, 0, c, evi_off, 50.0, 4.0, mask_tokens=mask)
+    np.testing.assert_allclose(got.cpu().double().numpy(), ref.detach().numpy(), atol=3e-5, rtol=1e-5)
+    dneg, devi = ops.local_pool_bwd(sim_t.to(DEV), dout.to(DEV), b, p, 0, c, evi_off, 50.0, 4.0, mask_tokens=mask)
+    want = neg.grad.permute(1, 0, 2).reshape(b * p, c).numpy()
+    scale = float(np.abs(want).max())
+    assert float(np.abs(dneg.cpu().double().numpy() - want).max()) <= 2e-5 * scale
+    if evidence:
+        want_e = evi.grad.permute(1, 0, 2).reshape(b * p, c).numpy()
+        assert float(np.abs(devi.cpu().double().numpy() - want_e).max()) <= 2e-5 * float(np.abs(want_e).max())
+    else:
+        assert devi is None
+
+
+def test_local_pool_many_positions(ops):
+    """ViT-L/14@336 geometry (576 patch positions, 80 classes, evidence prompts): the class-tiled kernel has no LDS limit on P x C."""
+    from oracle import clip_oracle as co
+    b, t, c, cp = 2, 577, 80, 128
+    sim = np.tanh(synth.normal(6, "sim", (b * t, 2 * cp), std=0.6)).astype(np.float32) * 0.5
+    sim_t = torch.from_numpy(sim)
+    pan = sim_t.view(b, t, 2 * cp)[:, 1:]
+    for evi_off in (-1, cp):
+        ref = co.local_pool(pan[:, :, :c].permute(1, 0, 2).double(), pan[:, :, cp:cp + c].permute(1, 0, 2).double() if evi_off >= 0 else None, 40.0, 4.0)
+        got = ops.local_pool(sim_t.to(DEV), b, t, 1, c, evi_off, 40.0, 4.0)
+        np.testing.assert_allclose(got.cpu().double().numpy(), ref.numpy(), atol=3e-5, rtol=1e-5)
+
+
+def _dense_trainer(tag, dt_name):
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)", "TRAINER.Caption.PREC", dt_name,
+                         "TRAIN.MODEL", "DenseCLIP", "TRAIN.LOSSFUNC", "double_ranking", "OPTIM.WARMUP_EPOCH", "0", "OPTIM.LR", "0.0",
+                         "TRAINER.Caption.use_evidence", str(tag == "evidence_ema"), "TRAIN.ema", str(tag == "evidence_ema"), "TRAIN.momentum", "0.995"])
+    return build_trainer(cfg)
+
+
+@pytest.mark.parametrize("tag", ["plain", "evidence_ema"])
+def test_dense_clip_caption_step_against_the_reference(ops, golden_dir, tag):
+    """The tuning step every shipped config runs (TRAIN.MODEL = DenseCLIP: model(None, captions), double_ranking on both heads, the
+    EMA distillation term) on the HIP path, fp32, against tests/golden/caption_branch.npz - scores, loss and the gradients w.r.t.
+    ctx / ctx_double / ctx_evidence that torch autograd produced through the REFERENCE's own forward and loss lines."""
+    g = np.load(os.path.join(golden_dir, "caption_branch.npz"))
+    tr = _dense_trainer(tag, "fp32")
+    model = tr.model_default
+    width = synth.TINY.transformer_width
+    pl = model.prompt_learner
+    with torch.no_grad():
+        for i, prm in enumerate((pl.ctx, pl.ctx_double, pl.ctx_evidence)):
+            prm.copy_(torch.from_numpy(synth.make_ctx(16, width, seed=i)))
+        if tag == "evidence_ema":
+            plm = model.prompt_learner_m
+            for name, prm in (("ctx", plm.ctx), ("ctx_double", plm.ctx_double), ("ctx_evidence", plm.ctx_evidence)):
+                prm.copy_(torch.from_numpy(g[f"{tag}.m_{name}_before"]))
+    model.train()
+    caps, label = torch.from_numpy(g["captions"]).to(DEV), torch.from_numpy(g["label"]).to(DEV)
+    out, local, img_feats, txt_feats, out_m, local_m = model(None, caps)
+    assert img_feats.shape == (77, caps.shape[0], synth.TINY.embed_dim) and txt_feats.shape == (80, synth.TINY.embed_dim)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g[f"{tag}.logits"], atol=1e-4, rtol=0)
+    np.testing.assert_allclose(local.detach().cpu().numpy(), g[f"{tag}.logits_local"], atol=2e-4, rtol=2e-4)
+    if tag == "evidence_ema":
+        np.testing.assert_allclose(model.prompt_learner_m.ctx.cpu().numpy(), g[f"{tag}.m_ctx_after"], atol=1e-7, rtol=0)
+        np.testing.assert_allclose(out_m.cpu().numpy(), g[f"{tag}.logits_m"], atol=1e-4, rtol=0)
+        np.testing.assert_allclose(local_m.cpu().numpy(), g[f"{tag}.logits_local_m"], atol=2e-4, rtol=2e-4)
+    else:
+        assert out_m is None and local_m is None
+    # the trainer's own step: same loss, gradients left on the parameters (LR = 0: the step itself changes nothing)
+    with torch.no_grad():
+        if tag == "evidence_ema":
+            for name, prm in (("ctx", plm.ctx), ("ctx_double", plm.ctx_double), ("ctx_evidence", plm.ctx_evidence)):
+                prm.copy_(torch.from_numpy(g[f"{tag}.m_{name}_before"]))
+    summary = tr.forward_backward({"img": caps, "label": label})
+    assert summary["loss"] == pytest.approx(float(g[f"{tag}.loss"]), rel=1e-4)
+    if tag == "evidence_ema":
+        assert summary["r_loss"] == pytest.approx(float(g[f"{tag}.r_loss"]), rel=1e-4) and "ema_loss" in summary
+    for name, prm in (("ctx", pl.ctx), ("ctx_double", pl.ctx_double), ("ctx_evidence", pl.ctx_evidence)):
+        want = g[f"{tag}.grad_{name}"]
+        got = prm.grad.detach().cpu().numpy() if prm.grad is not None else np.zeros_like(want)
+        scale = max(float(np.abs(want).max()), 1e-6)
+        err = float(np.abs(got - want).max()) / scale
+        print(f"{tag} {name}: max |grad| {scale:.3e}, relative error {err:.2e}")
+        assert err <= 2e-4, name
+    with pytest.raises(TypeError):
+        tr.forward_backward({"img": torch.zeros(2, 3, 32, 32, device=DEV), "label": label[:2]})
+
+
+@pytest.mark.parametrize("dt_name", ["fp16", "bf16"])
+def test_dense_clip_caption_step_at_size(ops, golden_dir, dt_name):
+    """BASELINE configs[2] geometry for the caption feed: ViT-B/16 text tower, 512 captions, 16-bit, evidence prompts + EMA: finite
+    loss, the three gradients agree in direction with autograd through the fp32 oracle on a 32-caption slice."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    from oracle import clip_oracle as co
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "ViT-B/16", "MODEL.BACKBONE.PATH", "synthetic:0:cond", "TRAINER.Caption.PREC", dt_name, "TRAIN.MODEL", "DenseCLIP",
+                         "TRAIN.LOSSFUNC", "double_ranking", "OPTIM.WARMUP_EPOCH", "0", "OPTIM.LR", "0.0", "TRAINER.Caption.use_evidence", "True",
+                         "TRAIN.ema", "True"])
+    tr = build_trainer(cfg)
+    model = tr.model_default
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    base = torch.from_numpy(t["tokens_photo"])
+    caps = base[torch.arange(512) % 80].contiguous()
+    label = torch.zeros(512, 80)
+    label[torch.arange(512), torch.arange(512) % 80] = 1.0
+    summary = tr.forward_backward({"img": caps.to(DEV), "label": label.to(DEV)})
+    assert np.isfinite(summary["loss"]) and np.isfinite(summary["ema_loss"])
+    pl = model.prompt_learner
+    grads = [p.grad.detach().float().cpu() for p in (pl.ctx, pl.ctx_double, pl.ctx_evidence)]
+    assert all(torch.isfinite(gr).all() and float(gr.abs().max()) > 0 for gr in grads)
+    # direction check on a slice (the fp32 oracle of 512 captions through a 12-layer tower is minutes of CPU): same step, 32 captions
+    sub = 32
+    tr2_summary = None
+    for p in (pl.ctx, pl.ctx_double, pl.ctx_evidence):
+        p.grad = None
+    model.ema = False            # ranking terms only: the distillation term's 10000x weight is a separate, golden-tested path
+    tr2_summary = tr.forward_backward({"img": caps[:sub].to(DEV), "label": label[:sub].to(DEV)})
+    sd = synth.make_state_dict(synth.VIT_B16, seed=0, dist="cond")
+    toks = torch.from_numpy(t["tokens_ctx16"])
+    prefix, suffix = co.prompt_buffers(toks, sd, 16)
+    ctx = [p.detach().float().cpu().clone().requires_grad_(True) for p in (pl.ctx, pl.ctx_double, pl.ctx_evidence)]
+    out, local = co.dense_clip_forward_captions(caps[:sub], sd, ctx[0], ctx[1], ctx[2], prefix, suffix, toks, 50.0, 4.0)
+    loss = co.double_ranking_loss(out, local, label[:sub])
+    loss.backward()
+    assert tr2_summary["loss"] == pytest.approx(float(loss), rel=5e-2)
+    for name, p, c in zip(("ctx", "ctx_double", "ctx_evidence"), (pl.ctx, pl.ctx_double, pl.ctx_evidence), ctx):
+        cos = float(torch.nn.functional.cosine_similarity(p.grad.detach().float().cpu().flatten().double(), c.grad.flatten().double(), dim=0))
+        print(f"{dt_name} {name}: cosine with oracle autograd {cos:.5f}")
+        assert cos >= (0.97 if dt_name == "fp16" else 0.90), name

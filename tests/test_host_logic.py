@@ -422,3 +422,59 @@ def test_bench_label_index_evidence():
     assert "outside the error band" in bench.accuracy_gate(dict(ev2, hip=50.0, oracle_fp32=50.0), "fp16")
     same = bench.label_index_evidence(ref, ref)
     assert same["top1_agree"] == 1.0 and same["top1_disagreements"] == [] and same["top1_disagreements_all_inside_band"]
+
+
+def _bpe_vocab():
+    v = os.environ.get("LECLIP_BPE_VOCAB") or REF_BPE
+    return v if os.path.exists(v) else None
+
+
+def test_prompt_cache_holds_the_reference_tokenizers_ids(golden_dir):
+    """clip/prompt_cache.json is what clip.tokenize answers from when no merge table is installed (the GPU box): every entry must
+    be the id sequence the REFERENCE tokenizer gives for its key (fixture generated by oracle/make_golden.py), and tokenize() on
+    the cache path must reproduce the class-prompt fixtures.  Runs everywhere - no merge table needed."""
+    import json
+    from leclip_amd.clip import clip as C
+    g = np.load(os.path.join(golden_dir, "tokens_multiscript.npz"))
+    with open(C._CACHE_PATH) as f:
+        cache = json.load(f)
+    keys = [str(k) for k in g["cache_keys"]]
+    assert sorted(cache) == keys
+    for k, row, n in zip(keys, g["cache_ids"], g["cache_lengths"]):
+        assert cache[k] == row[:n].tolist(), k
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    names = [str(c).replace("_", " ") for c in t["classnames"]]
+    prefix = " ".join(["X"] * 16)
+    ids = [[C.SOT_TOKEN] + C._cached_ids(f"a photo of a {c}.") + [C.EOT_TOKEN] for c in names]
+    assert all(row[:len(v)].tolist() == v and not row[len(v):].any() for row, v in zip(t["tokens_photo"], ids))
+    ids = [[C.SOT_TOKEN] + C._cached_ids(f"{prefix} {c}.") + [C.EOT_TOKEN] for c in names]
+    assert all(row[:len(v)].tolist() == v and not row[len(v):].any() for row, v in zip(t["tokens_ctx16"], ids))
+    with pytest.raises(FileNotFoundError):
+        C._cached_ids("a sentence nobody cached")
+
+
+@pytest.mark.skipif(_bpe_vocab() is None, reason="needs the CLIP merge table (LECLIP_BPE_VOCAB, or the reference's copy in the build container)")
+def test_tokenizers_on_the_reference_multiscript_fixture(golden_dir):
+    """240 seeded multi-script strings tokenised by the reference's SimpleTokenizer (oracle/make_golden.py): the Python tokenizer and
+    the native C++ tokenizer (leclip_bpe_*) must give the same ids on the real merge table."""
+    from leclip_amd.clip import clip as C
+    from leclip_amd.clip.simple_tokenizer import SimpleTokenizer
+    g = np.load(os.path.join(golden_dir, "tokens_multiscript.npz"))
+    texts = [str(s) for s in g["texts"]]
+    want = [row[:n].tolist() for row, n in zip(g["ids"], g["lengths"])]
+    assert len(texts) >= 200
+    py = SimpleTokenizer(_bpe_vocab())
+    nat = C.NativeTokenizer(_bpe_vocab())
+    refused = 0
+    for t, w in zip(texts, want):
+        assert py.encode(t) == w, repr(t)
+        try:
+            assert nat.encode(t) == w, repr(t)
+        except NotImplementedError:
+            refused += 1
+    assert refused == 0          # the fixture holds no '&' and no context-dependent case mapping: nothing is handed back to Python
+    rows = nat.tokenize(texts, 77, truncate=True).numpy()
+    for row, w in zip(rows, want):
+        ids = ([C.SOT_TOKEN] + w + [C.EOT_TOKEN])[:77]
+        ids[-1] = C.EOT_TOKEN
+        assert row[:len(ids)].tolist() == ids and not row[len(ids):].any()

@@ -162,3 +162,38 @@ def test_local_pool_against_reference_slice(golden_dir):
     ln, le = torch.from_numpy(g["n4.logits_neg"]), torch.from_numpy(g["n4.logits_evidence"])
     np.testing.assert_allclose(co.local_pool(ln, None, 40.0, 4.0).numpy(), g["n4.logits_local.plain"], atol=1e-6, rtol=1e-6)
     np.testing.assert_allclose(co.local_pool(ln, le, 40.0, 4.0).numpy(), g["n4.logits_local.evidence"], atol=1e-9, rtol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["plain", "evidence_ema"])
+def test_caption_training_branch_and_its_gradients(golden_dir, tag):
+    """oracle.dense_clip_forward_captions + double_ranking_loss against the reference's own lines (DenseCLIP.forward :473-541,
+    loss :806-815, executed by make_golden.py on the reference's TextEncoder / PromptLearner): scores, loss and - through torch
+    autograd - the gradients w.r.t. ctx, ctx_double and ctx_evidence."""
+    g = np.load(os.path.join(golden_dir, "caption_branch.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    sd = {k: torch.from_numpy(v) if isinstance(v, np.ndarray) else v for k, v in _sd(synth.TINY, 1, "cond").items()}
+    toks = torch.from_numpy(t["tokens_ctx16"])
+    prefix, suffix = co.prompt_buffers(toks, sd, 16)
+    width = synth.TINY.transformer_width
+    evi = tag == "evidence_ema"
+    ctx = [torch.from_numpy(synth.make_ctx(16, width, seed=i)).requires_grad_(True) for i in range(3)]
+    caps, label = torch.from_numpy(g["captions"]), torch.from_numpy(g["label"])
+    out, local = co.dense_clip_forward_captions(caps, sd, ctx[0], ctx[1], ctx[2] if evi else None, prefix, suffix, toks, 50.0, 4.0)
+    np.testing.assert_allclose(out.detach().numpy(), g[f"{tag}.logits"], atol=2e-5, rtol=0)
+    np.testing.assert_allclose(local.detach().numpy(), g[f"{tag}.logits_local"], atol=1e-4, rtol=1e-4)
+    out_m = local_m = None
+    if evi:     # the momentum copy after one update: m <- 0.995 m + 0.005 p
+        cm = [0.995 * torch.from_numpy(g[f"{tag}.m_{n}_before"]) + 0.005 * c.detach() for n, c in zip(("ctx", "ctx_double", "ctx_evidence"), ctx)]
+        np.testing.assert_allclose(cm[0].numpy(), g[f"{tag}.m_ctx_after"], atol=1e-7, rtol=0)
+        with torch.no_grad():
+            out_m, local_m = co.dense_clip_forward_captions(caps, sd, cm[0], cm[1], cm[2], prefix, suffix, toks, 50.0, 4.0)
+        np.testing.assert_allclose(out_m.numpy(), g[f"{tag}.logits_m"], atol=2e-5, rtol=0)
+        np.testing.assert_allclose(local_m.numpy(), g[f"{tag}.logits_local_m"], atol=1e-4, rtol=1e-4)
+    loss = co.double_ranking_loss(out, local, label, out_m, local_m)
+    assert float(loss) == pytest.approx(float(g[f"{tag}.loss"]), rel=2e-5)
+    loss.backward()
+    for name, c in zip(("ctx", "ctx_double", "ctx_evidence"), ctx):
+        want = g[f"{tag}.grad_{name}"]
+        got = c.grad.numpy() if c.grad is not None else np.zeros_like(want)
+        scale = max(float(np.abs(want).max()), 1e-6)
+        assert float(np.abs(got - want).max()) <= 2e-4 * scale, name
