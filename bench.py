@@ -190,12 +190,17 @@ def main():
 
     # per-kernel-family durations from the HIP events recorded inside the timed region
     fam = {}
-    for name, fl, nb, e0, e1 in prof:
-        f = fam.setdefault(name, [0.0, 0, 0, 0])
-        f[0] += e0.elapsed_time(e1) * 1e-3
-        f[1] += fl
-        f[2] += nb
-        f[3] += 1
+    shapes = {}
+    for name, fl, nb, e0, e1, shape in prof:
+        sec = e0.elapsed_time(e1) * 1e-3
+        for key, table in ((name, fam), (shape if name == "gemm" and shape else None, shapes)):
+            if key is None:
+                continue
+            f = table.setdefault(key, [0.0, 0, 0, 0])
+            f[0] += sec
+            f[1] += fl
+            f[2] += nb
+            f[3] += 1
     g = fam.get("gemm", [1e-9, 0, 0, 1])
     gemm_tflops = g[1] / g[0] * 1e-12
     off = min(args.profile_every // 2, args.steps // 2) if args.profile_every > 0 else 0
@@ -226,6 +231,9 @@ def main():
                                     "that is why ms_per_step is below the sum of the kernel times" % (max(args.profile_every, 1), run_info["parts"]),
                      "sampled_step_ms": run_info["sampled_step_ms"]},   # one part + an event pair around each of its launches
         "kernels": kernels,
+        # the GEMM family per launch shape (same HIP events, sampled one-part steps): which of the four block GEMMs trails
+        "gemm_shapes": {k: {"launches_per_step": v[3] // prof_steps, "avg_us": v[0] / v[3] * 1e6, "tflops": v[1] / v[0] * 1e-12,
+                            "mfma_frac": v[1] / v[0] * 1e-12 / PEAK_MFMA_TFLOPS} for k, v in sorted(shapes.items(), key=lambda kv: -kv[1][0])},
         "env_overrides": overrides,
     }
 

@@ -68,7 +68,8 @@ int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const float* bias
  *    with ln_stats [M][2] = (mean, rstd) per row, ln_colsum[n] = sum_k W'[n,k], bias[n] = sum_k beta[k] W[n,k] + b[n]:
  *    algebraically clip/model.py:193-199 followed by F.linear, without materialising (or 16-bit rounding) LN(x).
  *  - stats_out != NULL: additionally writes, per output row and 64-column block, (sum, sum of squared deviations from
- *    the block mean) of the rounded outputs to stats_out [M][N/64][2]; leclip_ln_stats_finalize_fwd merges the blocks
+ *    the block mean) of the rounded outputs to stats_out [N/64][M][2] - SLOT-major: the rows a wave finishes together are contiguous
+ *    bytes of one slot, written with full-line stores (ABI 7; ABI 6 was row-major [M][N/64][2]); leclip_ln_stats_finalize_fwd merges the blocks
  *    (parallel-variance update) into (mean, rstd) for the next fused GEMM.  Plain stores in a fixed layout:
  *    deterministic, nothing to zero, no E[x^2] - mean^2 cancellation on rows with |mean| >> std. */
 int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
@@ -76,7 +77,7 @@ int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, co
                              int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy, leclip_act act,
                              leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream);
 /* The same fused-LayerNorm GEMM fed with the PRODUCER's block partials instead of finished statistics: ln_partials
- * [M][ln_slots][2] (ln_slots = K / 64) as written by a stats_out epilogue or by leclip_patch_embed_ln_fwd.  The function
+ * [ln_slots][M][2] (ln_slots = K / 64, slot-major) as written by a stats_out epilogue or by leclip_patch_embed_ln_fwd.  The function
  * merges them (leclip_ln_stats_finalize_fwd's kernel) into ln_stats_ws [M][2] and runs the GEMM: one C call per consumer.
  * (Merging inside the 256x256 GEMM kernel was built and measured in round 2 and costs more than the launch it saves: the
  * specialised LayerNorm-epilogue kernels have no registers left for a row's partials - DESIGN.md section 6.)
@@ -111,7 +112,7 @@ int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, const float* cl
                               const float* beta, void* X, float* stats_out, int64_t B, int R, int P, int width,
                               leclip_dtype img_dtype, leclip_dtype w_dtype, leclip_dtype x_dtype, float eps, void* workspace,
                               void* stream);
-/* stats_out (nullable) [B*T][width/64][2]: (sum, M2 about the block mean) of the stored rows per 64-column block - the block
+/* stats_out (nullable) [width/64][B*T][2] (slot-major): (sum, M2 about the block mean) of the stored rows per 64-column block - the block
  * partials the first residual block's fused LayerNorm merges in place (leclip_gemm_ln_partials_fwd), so that no separate
  * row-statistics pass runs over the fresh residual stream. */
 

@@ -382,20 +382,26 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
     const int d_model = a.heads * 64;
     const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
-    for (int r = tid >> 3; r < TP; r += 64) {
-        const int c = tid & 7;
-        v8 kv, vv;
-        if (r < a.T) {
-            const T* row = base + (int64_t)r * a.ld_qkv;
-            kv = *(const v8*)(row + d_model + c * 8);
-            vv = *(const v8*)(row + 2 * d_model + c * 8);
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { kv[i] = (T)0.f; vv[i] = (T)0.f; }
-        }
-        *(v8*)(sK + r * 128 + ((c ^ ((r >> 1) & 7)) << 4)) = kv;
-        *(v8*)(sV + r * 128 + ((c ^ (((r >> 1) & 1) << 2)) << 4)) = vv;
+    // Stage K and V by LDS-DMA, every piece (8 rows x 128 B) of the head in flight at once: TP / 4 pieces, TP / 32 per wave (20 at
+    // T = 577).  Round 2 staged through registers, one 64-row pass at a time - ten dependent HBM round trips per head in front of the
+    // first MFMA, a third of the kernel at T = 577.  The swizzles are applied to the per-lane SOURCE address; rows past T re-read
+    // row T - 1 (their keys are masked, their probabilities exactly 0), as in attn_heads_kernel.
+    for (int pc = wave; pc < TP / 4; pc += 8) {
+        const int isv = pc >= TP / 8 ? 1 : 0;
+        const int piece = pc - isv * (TP / 8);
+        const int row = piece * 8 + (lane >> 3);
+        const int p = lane & 7;
+        const int c = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+        const int grow = row < a.T ? row : a.T - 1;
+        const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + c * 8;
+        __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
     }
+    // the wave's first query block travels beside the K/V pieces; every later block's Q is requested one block ahead (the loads sat
+    // in front of each block's first MFMA in round 2: one exposed HBM round trip per 32 queries)
+    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5, nchunk = TP >> 7;
+    v8 qf[4];
+    if (wave < nqb) attn_load_q<T>(a, base, wave, lane, qf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
@@ -408,11 +414,10 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     for (int i = 0; i < 2; ++i)
         vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
 
-    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5, nchunk = TP >> 7;
     T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
     for (int qb = wave; qb < nqb; qb += 8) {
-        v8 qf[4];
-        attn_load_q<T>(a, base, qb, lane, qf);
+        v8 qn[4];
+        if (qb + 8 < nqb) attn_load_q<T>(a, base, qb + 8, lane, qn);
         const int qi = qb * 32 + fr;
         const int qrow = qi < a.T ? qi : a.T - 1;
         const int klimit = a.causal ? qrow : a.T - 1;
@@ -430,6 +435,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
             for (int kt = 0; kt < 4; ++kt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
+                if (key0 + kt * 32 > a.T - 1) continue;      // a key tile wholly past T (wave-uniform): no MFMA, masked below
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const v8 kf = *(const v8*)(kbase[s] + (key0 + kt * 32) * 128);
@@ -469,6 +475,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2) {
+                    if (key0 + kt * 32 > a.T - 1) continue;  // every probability of the tile is exactly 0
                     v8 pf;
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
@@ -497,6 +504,10 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
                     for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
                     *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
                 }
+        }
+        if (qb + 8 < nqb) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = qn[s];
         }
     }
 }

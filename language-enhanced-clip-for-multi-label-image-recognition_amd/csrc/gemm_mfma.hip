@@ -231,9 +231,6 @@ extern "C" int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const f
                                            int64_t ldy, leclip_act act, leclip_dtype ab_dtype, leclip_dtype res_dtype,
                                            leclip_dtype y_dtype, void* stream);
 bool leclip_gemm256_eligible(int64_t M, int N, int K);
-bool leclip_gemm_x2_eligible(int64_t M, int N, int K, const EpiParams& e, int ab_dtype);
-int leclip_gemm_x2_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi,
-                          int ab_dtype, hipStream_t s);
 int leclip_gemm256_cus();
 int launch_128(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi,
                int ab_dtype, hipStream_t s);
@@ -262,12 +259,6 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
     // One kernel family per call, chosen from (M, N, K) alone and covering every row: an image's result must not depend on
     // where its rows sit in the batch (round 1 sent the trailing tile rows of a large batch to the 128x128 kernel, whose
     // MFMA shape sums K in a different order - sharded logits then differed from unsharded ones in the last bits).
-#ifdef LECLIP_X2_MASK
-    {   // experiment: 256x128 tiles, two workgroups per CU, for the epilogue flavours selected by the mask (bit = PF)
-        const int pf = epi.res ? 1 : (epi.ln_stats ? 2 : 0);
-        if (((LECLIP_X2_MASK >> pf) & 1) && leclip_gemm_x2_eligible(M, N, K, epi, ab_dtype)) return leclip_gemm_x2_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
-    }
-#endif
     if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     return launch_128(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
 }
@@ -306,7 +297,7 @@ extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const 
     EpiParams e;
     e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
     e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0; e.stats_rows = 0;
     return leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, (hipStream_t)stream);
 }
 
@@ -345,7 +336,7 @@ extern "C" int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const f
     EpiParams e;
     e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
     e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = act; e.rowmap_P = 0;
-    e.ln_stats = ln_stats; e.ln_colsum = ln_colsum; e.stats_out = stats_out; e.stats_slots = N / 64;
+    e.ln_stats = ln_stats; e.ln_colsum = ln_colsum; e.stats_out = stats_out; e.stats_slots = N / 64; e.stats_rows = M;
     e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = ln_eps;
     if (ln_partials) {
         // The merge (Chan's parallel-variance update, ln_merge_partials) runs as its own small launch into ln_stats_ws.  Merging

@@ -439,9 +439,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #endif
     // Cross-tile pipelining (see PP::ktile): an even number of K-tiles keeps the stage parity across the tile boundary.
     const bool pipelined = (nk & 1) == 0 && !(DIAG(g.dbg) & 4) && !DIAG(g.no_xtile);
-    // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 16 partial-sum pairs)
+    // stores per wave issued by the specialised epilogue's unchecked path (16 output chunks, + 8 partial-sum stores: one per pass)
     // (+ the 8 loads of the second residual batch, which are younger than the next tile's prologue DMA as well)
-    constexpr int EPI_STORES = CFG >= 0 ? 16 * (1 + ((CFG >> 1) & 1)) + (PF == 1 ? 8 : 0) : 0;
+    constexpr int EPI_STORES = CFG >= 0 ? 16 + 8 * ((CFG >> 1) & 1) + (PF == 1 ? 8 : 0) : 0;
     int tile_it = 0;
     (void)tile_it;
     bool drain = CFG >= 0;   // false: the previous tile ended with exactly EPI_STORES stores after this tile's prologue DMA
@@ -751,7 +751,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                         const int n = en0 + wn * 64 + ccol;
                         const int64_t row_base = em0 + wm * 128 + crow;
                         T* optr = (T*)e.out + row_base * e.ldy + n;
-                        float* sptr = STATS ? e.stats_out + (row_base * e.stats_slots + (n >> 6)) * 2 : nullptr;
+                        // LayerNorm partials, slot-major [slot][row][2]: the pass's 16 rows are 128 contiguous bytes of this wave's slot;
+                        // lane (row r, 0) stores the pair of row r, lane (row r, 1) the pair of row r + 8 - ONE full-line store per pass
+                        f32x2 st2[2] = {{0.f, 0.f}, {0.f, 0.f}};
                         const int rd_off[2] = {crow * 64 + (ccol ^ (((crow >> 2) & 1) << 4)), (8 + crow) * 64 + (ccol ^ ((((8 + crow) >> 2) & 1) << 4))};
                         if constexpr (PF == 1) {
                             if (q == 0) {   // second residual batch: issued before any store of this tile
@@ -760,7 +762,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                             }
                             if (q == 4) {   // ... and needed from here on: everything but the stores issued since must be back
                                 if (decltype(check)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (store count varies)
-                                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (1 + STATS)) : "memory");
+                                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + STATS)) : "memory");
 #pragma unroll
                                 for (int qu = 8; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
                             }
@@ -783,8 +785,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                                 ln[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mean_l)));
                                 ln[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rstd_l)));
                             }
-                            epi_fast_chunk<T, PF, ACT, STATS>(vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], ln,
-                                                              optr + (int64_t)roff * e.ldy, STATS ? sptr + (int64_t)roff * e.stats_slots * 2 : nullptr);
+                            epi_fast_chunk<T, PF, ACT, STATS>(vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], ln, optr + (int64_t)roff * e.ldy, st2[u]);
+                        }
+                        if constexpr (STATS == 1) {
+                            const int sel = lane_q & 7;
+                            const int64_t srow = row_base + q * 16 + (sel & 1) * 8;
+                            if (sel < 2 && (!decltype(check)::value || srow < g.M) && !decltype(nostore)::value)
+                                *(f32x2*)(e.stats_out + ((int64_t)(n >> 6) * e.stats_rows + srow) * 2) = sel ? st2[1] : st2[0];
                         }
                     }
                 };

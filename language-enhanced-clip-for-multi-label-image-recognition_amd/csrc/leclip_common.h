@@ -129,8 +129,12 @@ struct EpiParams {
     // Row statistics of the OUTPUT for the next LayerNorm: (sum, sum of squared deviations from the block mean) of the
     // rounded outputs per (row, 64-column block), written - not accumulated - so the result is deterministic and needs no
     // zeroing; leclip_ln_stats_finalize_fwd merges the blocks (parallel-variance update, no E[x^2] - mean^2 cancellation).
-    float* stats_out;        // [M][stats_slots][2] or null
+    // Layout SLOT-MAJOR, [stats_slots][stats_rows][2] (round 3): the 8 or 16 rows a wave finishes together are 64 / 128 contiguous
+    // bytes of one slot's column, one full-line store per epilogue pass - row-major [M][slots][2] made every pair a scattered 8-byte
+    // write at a 96-byte stride, 128 partial-line requests per wave and tile (14 % of the residual GEMMs).
+    float* stats_out;        // [stats_slots][stats_rows][2] or null
     int stats_slots;
+    int64_t stats_rows;      // rows of the partials tensor (= M of the producing GEMM)
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;
@@ -246,7 +250,7 @@ __device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n,
         if ((threadIdx.x & 7) == 0) {
             f32x2 w;
             w[0] = s1; w[1] = m2;
-            *(f32x2*)(e.stats_out + (orow * e.stats_slots + (n >> 6)) * 2) = w;
+            *(f32x2*)(e.stats_out + ((int64_t)(n >> 6) * e.stats_rows + orow) * 2) = w;
         }
     }
 }
@@ -262,10 +266,10 @@ __device__ __forceinline__ float row8_sum(float x) {
 
 // Compile-time-specialised 8-wide epilogue step (the hot configurations: output and residual in the operand dtype T, no
 // row remap).  Same arithmetic, in the same order, as epi_chunk8 (leclip_common.h); no branches, no address arithmetic
-// beyond the two pointers handed in, row sums by DPP.
+// beyond the pointer handed in, row sums by DPP; STATS: the row's (sum, M2 about the block mean) comes back in `stat`.
 template <typename T, int PF, int ACT, int STATS>
 __device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[8], const float (&s8)[8], i32x4 res_val,
-                                               f32x2 ln_val, T* optr, float* sptr) {
+                                               f32x2 ln_val, T* optr, f32x2& stat) {
     typedef typename VecOf<T>::v8 v8;
     if constexpr (PF == 2) {
         const float mean = ln_val[0], rstd = ln_val[1];
@@ -300,11 +304,8 @@ __device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[
 #pragma unroll
         for (int c = 0; c < 8; ++c) { const float dlt = (float)o8[c] - mb; m2 = fmaf(dlt, dlt, m2); }
         m2 = row8_sum(m2);
-        if ((threadIdx.x & 7) == 0) {
-            f32x2 w;
-            w[0] = s1; w[1] = m2;
-            *(f32x2*)sptr = w;
-        }
+        stat[0] = s1;       // every one of the row's 8 lanes holds the pair; the caller stores two rows' pairs with one instruction
+        stat[1] = m2;
     }
 }
 

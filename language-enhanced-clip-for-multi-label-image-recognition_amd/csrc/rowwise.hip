@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const TI* __restrict_
                 if ((lane & 15) == 0) {
                     f32x2 w;
                     w[0] = s1; w[1] = m2;
-                    *(f32x2*)(stats_out + (row * (dim >> 6) + (i * 4 + (lane >> 4))) * 2) = w;
+                    *(f32x2*)(stats_out + ((int64_t)(i * 4 + (lane >> 4)) * rows + row) * 2) = w;     // slot-major [dim/64][rows][2]
                 }
             }
         }
@@ -209,10 +209,13 @@ __global__ __launch_bounds__(256) void ln_stats_finalize_kernel(const float* __r
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
     f32x4 v[LN_MERGE_MAXV];
-    const f32x4* p = (const f32x4*)(partials + r * slots * 2);
+    const f32x2* p = (const f32x2*)partials + r;       // slot-major [slots][rows][2]: consecutive threads read consecutive pairs of a slot
 #pragma unroll
     for (int i = 0; i < LN_MERGE_MAXV; ++i)
-        if (2 * i < slots) v[i] = p[i];
+        if (2 * i < slots) {
+            const f32x2 a = p[(int64_t)(2 * i) * rows], b = p[(int64_t)(2 * i + 1) * rows];
+            v[i][0] = a[0]; v[i][1] = a[1]; v[i][2] = b[0]; v[i][3] = b[1];
+        }
     *(f32x2*)(stats + 2 * r) = ln_merge_partials(v, slots, dim, eps);
 }
 
@@ -221,13 +224,13 @@ __global__ void ln_stats_finalize_generic_kernel(const float* __restrict__ parti
                                                  int dim, float eps) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= rows) return;
-    const f32x2* p = (const f32x2*)(partials + r * slots * 2);
+    const f32x2* p = (const f32x2*)partials + r;
     float s1 = 0.f;
-    for (int i = 0; i < slots; ++i) s1 += p[i][0];
+    for (int i = 0; i < slots; ++i) s1 += p[(int64_t)i * rows][0];
     const float mean = s1 / (float)dim;
     const float bn = (float)(dim / slots);
     float m2 = 0.f;
-    for (int i = 0; i < slots; ++i) { const f32x2 t = p[i]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
+    for (int i = 0; i < slots; ++i) { const f32x2 t = p[(int64_t)i * rows]; const float dlt = t[0] / bn - mean; m2 += fmaf(bn * dlt, dlt, t[1]); }
     stats[2 * r] = mean;
     stats[2 * r + 1] = rsqrtf(m2 / (float)dim + eps);
 }
@@ -555,7 +558,7 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
     EpiParams e;
     e.bias = nullptr; e.res = pos; e.out = X; e.ldr = width; e.ldy = width;
     e.res_dt = LECLIP_F32; e.out_dt = x_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = G * G;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0; e.stats_rows = 0;
     return leclip_gemm_dispatch(workspace, Wp, B * G * G, width, Kp, Kp, Kp, e, w_dtype, s);
 }
 
@@ -592,7 +595,7 @@ extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, cons
     EpiParams e;
     e.bias = nullptr; e.res = nullptr; e.out = conv; e.ldr = 0; e.ldy = width;
     e.res_dt = LECLIP_F32; e.out_dt = w_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = 0;
-    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f; e.stats_out = nullptr; e.stats_slots = 0; e.stats_rows = 0;
     rc = leclip_gemm_dispatch(workspace, Wp, n_rows, width, Kp, Kp, Kp, e, w_dtype, s);
     if (rc) return rc;
     const dim3 grid((unsigned)((B * T + 3) / 4)), block(256);

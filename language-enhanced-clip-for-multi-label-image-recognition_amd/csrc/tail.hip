@@ -296,7 +296,11 @@ __global__ void move_rows_kernel(const char* __restrict__ src, const int64_t* __
     const int64_t j = index[i];
     const char* s = src + (scatter ? i : j) * src_pitch;
     char* d = dst + (scatter ? j : i) * dst_pitch;
-    for (int k = threadIdx.x * 16; k < row_bytes; k += blockDim.x * 16) *(i32x4*)(d + k) = *(const i32x4*)(s + k);
+    if ((row_bytes & 15) == 0) {
+        for (int k = threadIdx.x * 16; k < row_bytes; k += blockDim.x * 16) *(i32x4*)(d + k) = *(const i32x4*)(s + k);
+    } else {      // 8-byte granules (the slot-major LayerNorm partials are rows of one (sum, M2) pair)
+        for (int k = threadIdx.x * 8; k < row_bytes; k += blockDim.x * 8) *(f32x2*)(d + k) = *(const f32x2*)(s + k);
+    }
 }
 
 // x[r, :] /= |x[r, :]|_2 in place (fp32 rows; one wave per row) - the patch-token features of the local branch
@@ -318,13 +322,16 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
 //   evidence: w = softmax_c(tmp * s * (max_c s + 1));  s <- s * w;  prob = softmax_p(tmp * e)      (winner-take-all)
 //   else:     prob = softmax_p(tmp * s)
 //   logits_local[c] = sum_p logit_scale * s[p, c] * prob[p, c]
+// (the winner-take-all softmax is evaluated as exp(k (s - s_ext)) / sum, s_ext = the element with the largest k s - the row maximum, or
+// the minimum where k < 0: under a masked position k s is ~5e9, where k s - max(k s) loses everything to rounding - and a contracted
+// fma(k, s, -zmax) even yields exp(+256); the difference of the similarities themselves is exact.)
 // One workgroup per image.  The classes are processed CT at a time (the softmax over p is independent per class; the
 // winner-take-all row softmax needs only a per-position scale k, maximum and denominator, taken in a first pass straight
 // from global memory), so the LDS footprint is P * CT * 8 bytes whatever P and C are (ViT-L/14@336: P = 576).
 __global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict__ sim, const int64_t* __restrict__ mask_tok, float* __restrict__ out,
                                                          int P, int C, int CT, int64_t ld, int64_t image_stride, int64_t mask_stride, int evi_off,
                                                          float tmp, float logit_scale) {
-    extern __shared__ float sm[];      // k[P] | zmax[P] | den[P] | bias[P] | s [P][CT] (| e [P][CT])
+    extern __shared__ float sm[];      // k[P] | s_ext[P] | den[P] | bias[P] | s [P][CT] (| e [P][CT])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = sim + (int64_t)blockIdx.x * image_stride;
     float *rk = sm, *rz = sm + P, *rd = sm + 2 * P, *bias = sm + 3 * P, *s = sm + 4 * P, *e = s + P * CT;
@@ -334,17 +341,16 @@ __global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict
         for (int p = wave; p < P; p += 4) {      // per position: scale, maximum and denominator of softmax_c(tmp * s * (max + 1))
             const float* row = src + (int64_t)p * ld;
             const float b = bias[p];
-            float mx = -INFINITY;
-            for (int c = lane; c < C; c += 64) mx = fmaxf(mx, row[c] + b);
+            float mx = -INFINITY, mn = INFINITY;
+            for (int c = lane; c < C; c += 64) { mx = fmaxf(mx, row[c] + b); mn = fminf(mn, row[c] + b); }
             mx = wave_max(mx);
+            mn = -wave_max(-mn);
             const float k = tmp * (mx + 1.0f);
-            float zmax = -INFINITY;
-            for (int c = lane; c < C; c += 64) zmax = fmaxf(zmax, k * (row[c] + b));
-            zmax = wave_max(zmax);
+            const float vext = k >= 0.f ? mx : mn;      // the element whose k * s is largest
             float den = 0.f;
-            for (int c = lane; c < C; c += 64) den += expf(k * (row[c] + b) - zmax);
+            for (int c = lane; c < C; c += 64) den += expf(k * ((row[c] + b) - vext));
             den = wave_sum(den);
-            if (lane == 0) { rk[p] = k; rz[p] = zmax; rd[p] = den; }
+            if (lane == 0) { rk[p] = k; rz[p] = vext; rd[p] = den; }
         }
         __syncthreads();
     }
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict
             const int p = i / ct, c = i - p * ct;
             const float v = src[(int64_t)p * ld + c0 + c] + bias[p];
             if (evi_off >= 0) {
-                s[p * CT + c] = v * (expf(rk[p] * v - rz[p]) / rd[p]);
+                s[p * CT + c] = v * (expf(rk[p] * (v - rz[p])) / rd[p]);
                 e[p * CT + c] = src[(int64_t)p * ld + evi_off + c0 + c] + bias[p];
             } else {
                 s[p * CT + c] = v;
@@ -387,7 +393,7 @@ __global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict
 __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __restrict__ sim, const int64_t* __restrict__ mask_tok, const float* __restrict__ dout,
                                                              float* __restrict__ dneg, float* __restrict__ devi, int P, int C, int64_t ld,
                                                              int64_t image_stride, int64_t mask_stride, int evi_off, float tmp, float logit_scale) {
-    extern __shared__ float sm[];      // k[P] | zmax[P] | den[P] | bias[P] | amax[P] | cmx[C] | cden[C] | cm[C] | s [P][C] | g [P][C] (| e [P][C])
+    extern __shared__ float sm[];      // k[P] | s_ext[P] | den[P] | bias[P] | amax[P] | cmx[C] | cden[C] | cm[C] | s [P][C] | g [P][C] (| e [P][C])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = sim + (int64_t)blockIdx.x * image_stride;
     float *rk = sm, *rz = sm + P, *rd = sm + 2 * P, *bias = sm + 3 * P;
@@ -413,13 +419,14 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(am, o); am = t < am ? t : am; }
             const float k = tmp * (mx + 1.0f);
-            float zmax = -INFINITY;
-            for (int c = lane; c < C; c += 64) zmax = fmaxf(zmax, k * row[c]);
-            zmax = wave_max(zmax);
+            float mn = INFINITY;
+            for (int c = lane; c < C; c += 64) mn = fminf(mn, row[c]);
+            mn = -wave_max(-mn);
+            const float vext = k >= 0.f ? mx : mn;
             float den = 0.f;
-            for (int c = lane; c < C; c += 64) den += expf(k * row[c] - zmax);
+            for (int c = lane; c < C; c += 64) den += expf(k * (row[c] - vext));
             den = wave_sum(den);
-            if (lane == 0) { rk[p] = k; rz[p] = zmax; rd[p] = den; ramax[p] = am; }
+            if (lane == 0) { rk[p] = k; rz[p] = vext; rd[p] = den; ramax[p] = am; }
         }
         __syncthreads();
     }
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
         for (int p = 0; p < P; ++p) {
             const float w = expf(tmp * z[p * C + c] - mx);
             float sv = s[p * C + c];
-            if (evi) sv *= expf(rk[p] * sv - rz[p]) / rd[p];
+            if (evi) sv *= expf(rk[p] * (sv - rz[p])) / rd[p];
             den += w;
             num = fmaf(w, sv, num);
         }
@@ -448,7 +455,7 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
         if (!evi) {
             dn[i] = gs * (1.0f + tmp * (s[i] - cm[c]));
         } else {
-            const float sv = s[i] * (expf(rk[p] * s[i] - rz[p]) / rd[p]);
+            const float sv = s[i] * (expf(rk[p] * (s[i] - rz[p])) / rd[p]);
             de[i] = gs * tmp * (sv - cm[c]);
             g[i] = gs;
         }
@@ -460,17 +467,17 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
         const float* gr = g + p * C;
         const float k = rk[p], zm = rz[p], dnm = rd[p];
         float H = 0.f;
-        for (int c = lane; c < C; c += 64) H = fmaf(gr[c] * row[c], expf(k * row[c] - zm) / dnm, H);
+        for (int c = lane; c < C; c += 64) H = fmaf(gr[c] * row[c], expf(k * (row[c] - zm)) / dnm, H);
         H = wave_sum(H);
         float S = 0.f;
         for (int c = lane; c < C; c += 64) {
-            const float w = expf(k * row[c] - zm) / dnm;
+            const float w = expf(k * (row[c] - zm)) / dnm;
             S = fmaf(w * (gr[c] * row[c] - H), row[c], S);
         }
         S = wave_sum(S);
         const int am = ramax[p];
         for (int c = lane; c < C; c += 64) {
-            const float w = expf(k * row[c] - zm) / dnm;
+            const float w = expf(k * (row[c] - zm)) / dnm;
             const float u = w * (gr[c] * row[c] - H);
             dn[p * C + c] = fmaf(k, u, gr[c] * w) + (c == am ? tmp * S : 0.0f);
         }
@@ -533,8 +540,9 @@ static int move_rows(const void* src, const int64_t* index, void* dst, int64_t n
         return LECLIP_E_INVALID;
     }
     const int esz = dtype_size(dtype);
-    if (((int64_t)dim * esz) % 16 || (ld_src * esz) % 16 || (ld_dst * esz) % 16 || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
-        leclip_set_error("%s: rows must be multiples of 16 bytes, 16-byte aligned", what);
+    const int gran = ((int64_t)dim * esz) % 16 == 0 && (ld_src * esz) % 16 == 0 && (ld_dst * esz) % 16 == 0 && !((uintptr_t)src & 15) && !((uintptr_t)dst & 15) ? 16 : 8;
+    if (((int64_t)dim * esz) % gran || (ld_src * esz) % gran || (ld_dst * esz) % gran || ((uintptr_t)src & (gran - 1)) || ((uintptr_t)dst & (gran - 1))) {
+        leclip_set_error("%s: rows must be multiples of 8 bytes, 8-byte aligned (16 for the wide path)", what);
         return LECLIP_E_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;

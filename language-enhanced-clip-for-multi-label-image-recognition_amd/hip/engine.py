@@ -83,13 +83,16 @@ class _Workspace:
         self.u = torch.empty((rows, 4 * d), dtype=dtype, device=device)
         # fused-LayerNorm path: per-row (mean, rstd) and the epilogue's partial sums per 64-column block
         self.stats = torch.empty((rows, 2), dtype=torch.float32, device=device)
-        self.partials = torch.empty((rows, d // 64, 2), dtype=torch.float32, device=device)
+        # slot-major [d/64][rows][2]: the rows a wave finishes together are contiguous bytes of one slot (one full-line store per pass)
+        self.partials = torch.empty((d // 64, rows, 2), dtype=torch.float32, device=device)
         if batch > 0:   # image tower: the last block's class-token rows (run_blocks, ``cls_last``)
             self.cls_x = torch.empty((batch, d), dtype=dtype, device=device)
             self.cls_u = torch.empty((batch, 4 * d), dtype=dtype, device=device)
             self.cls_stats = torch.empty((batch, 2), dtype=torch.float32, device=device)
-            self.cls_partials = torch.empty((batch, d // 64, 2), dtype=torch.float32, device=device)
+            self.cls_partials = torch.empty((d // 64, batch, 2), dtype=torch.float32, device=device)
             self.cls_index = (torch.arange(batch, device=device, dtype=torch.int64) * (rows // batch)).contiguous()
+            # the class rows' pairs inside the flat [d/64 * rows, 2] view of the partials: slot * rows + class row
+            self.cls_pair_index = (torch.arange(d // 64, device=device, dtype=torch.int64)[:, None] * rows + self.cls_index[None, :]).reshape(-1).contiguous()
 
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
@@ -98,7 +101,7 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
-    epilogue emits per-row block partials (sum, M2 about the block mean per 64 columns), a 5 us merge kernel (launched by
+    epilogue emits per-row block partials (sum, M2 about the block mean per 64 columns; slot-major [d/64][rows][2]), a 5 us merge kernel (launched by
     the consumer's C entry point) turns them into (mean, rstd), and the consuming GEMM - fed the raw residual rows and
     gamma-folded weights - normalises in its epilogue: LN(x) is never written to HBM nor rounded to 16 bits.
     ``have_partials``: ``ws.partials`` already holds the partials of ``x`` (written by the fused
@@ -129,7 +132,7 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
                 if "ln_partials" in src:
                     # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only
                     ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
-                    ops.gather_rows(ws.partials.view(batch * tokens, -1), ws.cls_index, out=ws.cls_partials.view(batch, -1))
+                    ops.gather_rows(ws.partials.view(-1, 2), ws.cls_pair_index, out=ws.cls_partials.view(-1, 2))
                     ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], **cls)
                 else:   # (a one-block tower without fused patch statistics: the whole qkv GEMM)
                     ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)

@@ -16,7 +16,7 @@ _DT = {torch.float32: _capi.F32, torch.float16: _capi.F16, torch.bfloat16: _capi
 
 
 # Optional per-launch timing hook (bench.py): when a list is installed, gemm()/attention()/layernorm() bracket
-# their launch with HIP events on the launch stream and append (kernel family, algorithmic flops, bytes, e0, e1).
+# their launch with HIP events on the launch stream and append (kernel family, algorithmic flops, bytes, e0, e1, shape label).
 _PROFILE = None
 
 
@@ -26,10 +26,10 @@ def set_profile(sink):
 
 
 class _Timed:
-    __slots__ = ("name", "flops", "nbytes", "e0")
+    __slots__ = ("name", "flops", "nbytes", "e0", "shape")
 
-    def __init__(self, name, flops, nbytes):
-        self.name, self.flops, self.nbytes = name, flops, nbytes
+    def __init__(self, name, flops, nbytes, shape=""):
+        self.name, self.flops, self.nbytes, self.shape = name, flops, nbytes, shape
 
     def __enter__(self):
         if _PROFILE is not None:
@@ -41,7 +41,7 @@ class _Timed:
         if _PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            _PROFILE.append((self.name, self.flops, self.nbytes, self.e0, e1))
+            _PROFILE.append((self.name, self.flops, self.nbytes, self.e0, e1, self.shape))
         return False
 
 
@@ -116,7 +116,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         assert bias.dtype == torch.float32 and bias.numel() == n
         _dev(bias, "bias")
     nbytes = (m * k + n * k) * a.element_size() + m * n * out.element_size() + (m * n * residual.element_size() if residual is not None else 0)
-    with _Timed("gemm", 2 * m * n * k, nbytes):
+    with _Timed("gemm", 2 * m * n * k, nbytes, f"M{m} N{n} K{k}"):
         _capi.check(_capi.load().leclip_gemm_bias_act_res_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), m, n, k,
                                                               lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
                                                               dtype_code(out.dtype), _stream()), "gemm")
@@ -288,10 +288,10 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
             out: Optional[torch.Tensor] = None, ln_partials: Optional[torch.Tensor] = None, ln_stats_ws: Optional[torch.Tensor] = None,
             eps: float = 1e-5) -> torch.Tensor:
     """GEMM with LayerNorm folded around it (leclip_gemm_ln_partials_fwd).  The A-side LayerNorm statistics come either as
-    ``ln_stats`` [M,2] (mean, rstd) or as the producer's block partials ``ln_partials`` [M, K/64, 2]; the C entry point then ALWAYS
+    ``ln_stats`` [M,2] (mean, rstd) or as the producer's block partials ``ln_partials`` [K/64, M, 2] (slot-major); the C entry point then ALWAYS
     launches the separate merge kernel (ln_stats_finalize_kernel, same stream, in front of the GEMM) that turns the partials into
     (mean, rstd) in ``ln_stats_ws`` [M,2], which the caller provides - an in-kernel merge was built twice and rejected for register
-    spills.  ``stats_out`` [M, N/64, 2] receives the output rows' block partials (sum, M2 about the block
+    spills.  ``stats_out`` [N/64, M, 2] receives the output rows' block partials (sum, M2 about the block
     mean) for the next LayerNorm."""
     m, k, lda = _rows2d(a, "a")
     n, kw, ldw = _rows2d(w, "w")
@@ -306,16 +306,16 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
         rdt = dtype_code(residual.dtype)
     slots = 0
     if ln_partials is not None:
-        slots = ln_partials.shape[1]
+        slots = ln_partials.shape[0]
         if ln_stats_ws is None:
             ln_stats_ws = torch.empty((m, 2), dtype=torch.float32, device=a.device)
-    for name, t, shape in (("ln_stats", ln_stats, (m, 2)), ("ln_colsum", ln_colsum, (n,)), ("stats_out", stats_out, (m, n // 64, 2)),
-                           ("bias", bias, (n,)), ("ln_partials", ln_partials, (m, k // 64, 2)), ("ln_stats_ws", ln_stats_ws, (m, 2))):
+    for name, t, shape in (("ln_stats", ln_stats, (m, 2)), ("ln_colsum", ln_colsum, (n,)), ("stats_out", stats_out, (n // 64, m, 2)),
+                           ("bias", bias, (n,)), ("ln_partials", ln_partials, (k // 64, m, 2)), ("ln_stats_ws", ln_stats_ws, (m, 2))):
         if t is not None:
             _dev(t, name)
             assert t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == shape, (name, tuple(t.shape), shape)
     nbytes = (m * k + n * k) * a.element_size() + m * n * out.element_size() + (m * n * residual.element_size() if residual is not None else 0)
-    with _Timed("gemm", 2 * m * n * k, nbytes):
+    with _Timed("gemm", 2 * m * n * k, nbytes, f"M{m} N{n} K{k}"):
         _capi.check(_capi.load().leclip_gemm_ln_partials_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(ln_stats), _ptr(ln_partials), slots,
                                                              _ptr(ln_stats_ws), eps, _ptr(ln_colsum), _ptr(residual), _ptr(out), _ptr(stats_out),
                                                              m, n, k, lda, ldw, ldr, ldy, act, dtype_code(a.dtype), rdt,
@@ -326,7 +326,7 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
 def ln_stats_finalize(partials: torch.Tensor, dim: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(partials, "partials")
     assert partials.dtype == torch.float32 and partials.dim() == 3 and partials.shape[2] == 2 and partials.is_contiguous()
-    rows, slots, _ = partials.shape
+    slots, rows, _ = partials.shape      # slot-major [slots][rows][2]
     if out is None:
         out = torch.empty((rows, 2), dtype=torch.float32, device=partials.device)
     with _Timed("ln_stats", 0, partials.numel() * 4 + rows * 8):

@@ -5,7 +5,7 @@
 
 Config assembly order is the reference's: defaults -> dataset yaml -> trainer yaml -> argparse -> free ``opts``, then
 freeze (``setup_cfg``, :145-166).  One process drives one GPU; under ``torchrun`` (WORLD_SIZE > 1) the process group is
-RCCL and evaluation is sharded with an all-gather of logits (``leclip_amd.parallel``).  The data pipeline of the
+RCCL and evaluation is sharded inside the trainer's ``test()`` with one all-gather of the epoch's scores (``leclip_amd.parallel``).  The data pipeline of the
 reference (Dassl dataset readers) is outside the hot path: the evaluation runs on the deterministic synthetic image set,
 with targets drawn from the scores of the FIXED zero-shot prompts (not from the scores under evaluation) and the result
 tagged as synthetic; ``--root`` / ``DATASET.ROOT`` is refused rather than ignored.
@@ -143,6 +143,8 @@ def zero_shot_teacher_labels(trainer, images_fn, n, batch, pos_frac=0.1):
 
 
 def main(argv=None):
+    import leclip_amd
+    leclip_amd.configure()      # hardware queues for the image engine's stream parts: before the first device call (see configure())
     ap = argparse.ArgumentParser()
     ap.add_argument("--root", type=str, default="", help="path to dataset")
     ap.add_argument("--output-dir", type=str, default="", help="output directory")
@@ -180,16 +182,11 @@ def main(argv=None):
     images_fn = lambda s, b: torch.from_numpy(synth.make_images(b, res, seed=1234, start=s))
     labels = zero_shot_teacher_labels(trainer, images_fn, args.num_images, cfg.DATALOADER.TEST.BATCH_SIZE)
     loader = _SyntheticLoader(args.num_images, cfg.DATALOADER.TEST.BATCH_SIZE, res)
-    name = trainer.get_model_names()[0]
-    trainer.set_model_mode("eval")
-    scorer = parallel.ShardedScorer(lambda x: trainer.model_inference(x, name)[0])
-    scores = []
-    with torch.no_grad():
-        for batch in loader:
-            scores.append(scorer.score_global(batch["img"].to(trainer.device)).float().cpu())
-    scores = torch.cat(scores).numpy()
-    evaluator.reset()
-    evaluator.process(torch.from_numpy(scores), torch.from_numpy(labels))
+    loader.labels = labels
+    # the trainer's own test loop (reference :589-732): sharded by rank under WORLD_SIZE > 1 - every rank scores its share of each
+    # batch, scores stay on the device, ONE all-gather per epoch, one asynchronous copy to pinned host memory (no per-batch .cpu())
+    trainer.test_loader = loader
+    trainer.test()
     out = None
     if rank == 0:
         print("=> synthetic evaluation set (N(0,1) images); targets = zero-shot fixed-prompt teacher, NOT a dataset result")

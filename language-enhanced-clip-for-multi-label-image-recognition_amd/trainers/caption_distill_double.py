@@ -723,6 +723,8 @@ class Caption_distill_double:
                 ev.synchronize()
             self.evaluator.process(out_h, lab, pos_h)
 
+        if self.world > 1:
+            return self._test_sharded(data_loader, names[0], mode, use_freq, to_host)
         pending = None
         for batch in data_loader:
             input, label, input_blocks = self.parse_batch_test(batch)
@@ -754,6 +756,111 @@ class Caption_distill_double:
             hand_over(pending)
         results = self.evaluator.evaluate()
         return list(results.values())[0]
+
+    def _test_sharded(self, data_loader, name, mode, use_freq, to_host):
+        """test() under WORLD_SIZE > 1 (the north star's sharded evaluation; the reference scores everything on every rank, :589-732).
+        Every rank iterates the same loader; of each batch rank r scores the images shard_bounds(B, r, world) and - of each scale's
+        flattened window list [B * W_s] (N2: ~305 forwards per image) - its contiguous share, so the window work is spread even when a
+        batch holds fewer images than there are ranks.  Scores stay on the device for the whole epoch: per image one row
+        [global | local | max over this rank's windows | -min | the same two for the local scores], -inf where this rank has nothing.
+        Windows enter the aggregation only through their per-class maximum and minimum (:654-660), and max / min over a union of
+        windows is the max / min of the parts' extrema, so ONE all-gather of the epoch's rows at the end (parallel.all_gather_rows;
+        RCCL over xGMI) followed by an elementwise maximum over ranks reproduces the single-process scores bit for bit - every
+        window's and every image's scores are batch-invariant.  Then the same aggregation kernel on (max, min), one
+        asynchronous copy to pinned host memory, and every rank's evaluator sees the whole set."""
+        from ..hip import ops
+        from .. import parallel
+        dev = self.device
+        ninf = float("-inf")
+        rows, labels = [], []
+        has_pos = has_win = False
+        n_cls = None
+        for batch in data_loader:
+            input, label, input_blocks = self.parse_batch_test(batch)
+            b = input.shape[0]
+            lo, hi = parallel.shard_bounds(b, self.rank, self.world)
+            res = self.model_inference(input[lo:hi].contiguous(), name)
+            out = res[0].float()
+            pos = res[1].float() if res[1] is not None else None
+            n_cls = out.shape[1]
+            if use_freq and pos is not None:
+                pos = ops.cooccurrence_adjust(pos, self.cooccurrence_matrix(), 0.5) if pos.shape[0] else pos
+            cols = [torch.full((b, n_cls), ninf, dtype=torch.float32, device=dev) for _ in range(6)]
+            cols[0][lo:hi] = out
+            if pos is not None:
+                has_pos = True
+                cols[1][lo:hi] = pos
+            if mode == "test" and input_blocks is not None:
+                has_win = True
+                ext = self._window_extrema(input_blocks, name, use_freq)
+                cols[2], cols[3] = ext[0], ext[1]
+                if ext[2] is not None:
+                    cols[4], cols[5] = ext[2], ext[3]
+            rows.append(torch.cat(cols, dim=1))
+            labels.append(label)
+        if not rows:
+            results = self.evaluator.evaluate()
+            return list(results.values())[0]
+        local = torch.cat(rows, dim=0).contiguous()                         # [N, 6 C] on the device
+        n = local.shape[0]
+        gathered = parallel.all_gather_rows(local)                          # the ONE collective of the epoch
+        full = gathered.view(self.world, n, -1).amax(dim=0)
+        c = n_cls
+        output, output_pos = full[:, :c].contiguous(), (full[:, c:2 * c].contiguous() if has_pos else None)
+        if has_win:
+            stack = torch.stack([full[:, 2 * c:3 * c], -full[:, 3 * c:4 * c]], dim=1).contiguous()         # [N, 2, C] = (max_w, min_w)
+            output = ops.window_aggregate(output, stack, threshold=0.3, weight=1.4)
+            if has_pos:
+                stack = torch.stack([full[:, 4 * c:5 * c], -full[:, 5 * c:6 * c]], dim=1).contiguous()
+                output_pos = ops.window_aggregate(output_pos, stack, threshold=0.3, weight=1.4)
+        out_h, pos_h = to_host(output), to_host(output_pos)
+        if output.is_cuda:
+            torch.cuda.current_stream(dev).synchronize()
+        self.evaluator.process(out_h, torch.cat(labels, dim=0), pos_h)
+        results = self.evaluator.evaluate()
+        return list(results.values())[0]
+
+    def _window_extrema(self, input_blocks, name, use_freq):
+        """This rank's share of a batch's windows -> per image (max over its windows, -min) of the global scores and, when the model has
+        a local branch, of the (co-occurrence-adjusted) local scores: [B, C] each, -inf for images none of whose windows fell to this rank."""
+        from ..hip import ops
+        from .. import parallel
+        chunk = max(int(self.cfg.DATALOADER.TEST.BATCH_SIZE), 1)
+        acc = None
+        for blk in input_blocks:
+            b, w = blk.shape[0], blk.shape[1]
+            flat = blk.reshape(b * w, *blk.shape[2:])
+            lo, hi = parallel.shard_bounds(b * w, self.rank, self.world)
+            res = [self.model_inference(flat[s:min(s + chunk, hi)].contiguous(), name) for s in range(lo, hi, chunk)]
+            parts = []
+            for k in (0, 1):
+                if not res or res[0][k] is None:
+                    parts.append(None)
+                    continue
+                sc = torch.cat([r[k].float() for r in res])
+                if k == 1 and use_freq:
+                    sc = ops.cooccurrence_adjust(sc, self.cooccurrence_matrix(), 0.5)
+                c = sc.shape[1]
+                hi_buf = torch.full((b * w, c), float("-inf"), dtype=torch.float32, device=sc.device)
+                lo_buf = torch.full((b * w, c), float("-inf"), dtype=torch.float32, device=sc.device)
+                hi_buf[lo:hi] = sc
+                lo_buf[lo:hi] = -sc
+                parts += [hi_buf.view(b, w, c).amax(dim=1), lo_buf.view(b, w, c).amax(dim=1)]
+            if len(parts) == 2:      # (no local branch / empty share)
+                parts = [parts[0], None, None, None] if parts[0] is None else parts + [None, None]
+            if parts[0] is None:
+                continue
+            if acc is None:
+                acc = parts
+            else:
+                acc = [a if p is None else (p if a is None else torch.maximum(a, p)) for a, p in zip(acc, parts)]
+        if acc is None:     # this rank got no window of this batch at all
+            b = input_blocks[0].shape[0]
+            model = getattr(self, f"model_{name}")
+            c = model.prompt_learner.n_cls
+            e = torch.full((b, c), float("-inf"), dtype=torch.float32, device=self.device)
+            return [e, e.clone(), None, None]
+        return acc
 
     # ------------------------------------------------------------------ checkpoints (dassl/utils/torchtools.py:27-82, 126-165)
     def save_model(self, epoch: int, directory: str, is_best: bool = False, model_name: str = ""):

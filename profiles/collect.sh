@@ -1,10 +1,10 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun):  bash profiles/collect.sh r02
+# Runs ON THE GPU BOX (via gpurun):  bash profiles/collect.sh r03
 # kernel-trace stats + separate PMC passes (never combined with other trace domains) for the benchmark command, the
 # ViT-L/14@336 large-model point (BASELINE configs[4], one GPU's share B=128) and the prompt-tuning step (configs[2]).
 # Raw output under gpurun_out/prof_<tag>/ ; `python profiles/summarize.py <tag>` turns it into the committed files.
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
@@ -24,8 +24,14 @@ echo pmc mem done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1 || exit 1
 echo pmc sq done
-VITL="python3 $R/bench.py --arch ViT-L/14@336px --batch 128 --steps 3 --warmup 1 --no-cpu-baseline --no-second-dtype"
+# ViT-L/14@336 (BASELINE configs[4], one GPU's share): --streams 1 so that a dispatch's duration is the kernel alone on the chip (the
+# round-2 trace was taken in two-part mode, where a small kernel's begin..end includes queueing behind the other part's persistent grid:
+# ln_stats_finalize_kernel read 112 us there)
+VITL="python3 $R/bench.py --arch ViT-L/14@336px --batch 128 --steps 3 --warmup 1 --no-cpu-baseline --no-second-dtype --streams 1"
 timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/vitl -- $VITL > $OUT/vitl.log 2>&1 || exit 1
+# attention counters (MFMA busy, LDS conflicts, issue stalls): ViT-L stream kernel and ViT-B heads kernel, their own pass
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq_vitl -- $VITL > $OUT/pmc_sq_vitl.log 2>&1 || exit 1
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm_vitl -- $VITL > $OUT/pmc_grbm_vitl.log 2>&1 || exit 1
 echo vitl done
 TUNE="python3 $R/bench.py --mode tune --dtype bf16 --steps 4 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tune -- $TUNE > $OUT/tune.log 2>&1 || exit 1

@@ -3,7 +3,7 @@
 <tag>_kernel_stats.csv, <tag>_pmc_summary.json, <tag>_vitl_kernel_stats.csv, <tag>_tune_kernel_stats.csv and the bench JSON lines.
     python profiles/summarize.py r02"""
 import collections, csv, glob, json, os, shutil, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
@@ -65,6 +65,61 @@ for name in ("attn_heads_kernel", "gemm_tn_128x128x64", "image_tail_kernel", "em
     f2, _ = by_kernel(counters("pmc_fetch"), name)
     w2, _ = by_kernel(counters("pmc_write"), name)
     out[name] = {"read_bytes_corrected": 2 * f2.get("FETCH_SIZE", 0) * 1024, "write_bytes": w2.get("WRITE_SIZE", 0) * 1024}
+# attention: SQ counters of the ViT-B heads kernel (same passes as the GEMM) and of the ViT-L/14@336 stream kernel (its own passes)
+sq_h, _ = by_kernel(counters("pmc_sq"), "attn_heads_kernel")
+g_h, _ = by_kernel(counters("pmc_grbm"), "attn_heads_kernel")
+out["attn_heads_kernel"].update({"SQ": sq_h, "GRBM_GUI_ACTIVE": g_h.get("GRBM_GUI_ACTIVE"),
+                                 "mfma_busy_frac_of_simd_cycles": sq_h.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(g_h.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)})
+if os.path.isdir(os.path.join(SRC, "pmc_sq_vitl")):
+    sq_s, _ = by_kernel(counters("pmc_sq_vitl"), "attn_stream_kernel")
+    g_s, _ = by_kernel(counters("pmc_grbm_vitl"), "attn_stream_kernel")
+    out["attn_stream_kernel (ViT-L/14@336, B=128)"] = {"SQ": sq_s, "GRBM_GUI_ACTIVE": g_s.get("GRBM_GUI_ACTIVE"),
+                                                       "mfma_busy_frac_of_simd_cycles": sq_s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(g_s.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)}
+
+
+# ---- the GEMM family per launch shape, from the per-dispatch kernel trace (the persistent grid is 256 workgroups for every shape, so
+# the shape is told by the kernel flavour and - for <T,1,2>, which serves out-proj and c_proj alternately - by the dispatch order
+# inside a forward, cross-checked against the bimodal durations)
+def per_shape(sub, out_name):
+    path = newest(os.path.join(SRC, sub, "*", "*_kernel_trace.csv"))
+    rows_ = sorted(csv.DictReader(open(path)), key=lambda r: int(r["Start_Timestamp"]))
+    shapes = collections.defaultdict(list)
+    alt = 0
+    for r in rows_:
+        n = r["Kernel_Name"]
+        if GEMM not in n:
+            continue
+        us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
+        if "Li2ELi0E" in n:
+            key = "qkv (LN fused) N=2304 K=768" if us > 100 else "text tower / small (LN fused)"
+        elif "Li2ELi1E" in n:
+            key = "c_fc (LN + QuickGELU fused) N=3072 K=768" if us > 150 else "text tower c_fc"
+        elif "Li1ELi2E" in n:
+            key = ("out_proj (+residual, +partials) N=768 K=768", "c_proj (+residual, +partials) N=768 K=3072")[alt & 1]
+            if (us > 150) != bool(alt & 1):      # order lost (e.g. a last block without partials in between): fall back to the duration
+                key = "c_proj (+residual, +partials) N=768 K=3072" if us > 150 else "out_proj (+residual, +partials) N=768 K=768"
+                alt = 1 if us > 150 else 0
+            alt += 1
+        elif "Li1ELi0E" in n:
+            key = "c_proj last block (+residual) N=768 K=3072" if us > 150 else "out_proj / small (+residual)"
+        elif "Li0ELi0E" in n:
+            key = "patch embedding GEMM (bias only)"
+        else:
+            key = "other flavour"
+        shapes[key].append(us)
+    flops = {"qkv": 2 * 50432 * 2304 * 768, "c_fc": 2 * 50432 * 3072 * 768, "out_proj (": 2 * 50432 * 768 * 768, "c_proj": 2 * 50432 * 768 * 3072}
+    with open(os.path.join(DST, out_name), "w") as f:
+        w = csv.writer(f)
+        w.writerow(["shape", "launches", "avg_us", "min_us", "max_us", "TFLOP/s (B=256)", "frac of 2516.6"])
+        for k, v in sorted(shapes.items(), key=lambda kv: -sum(kv[1])):
+            fl = next((x for p_, x in flops.items() if k.startswith(p_)), None)
+            avg = sum(v) / len(v)
+            tf = fl / avg * 1e-6 if fl else ""
+            w.writerow([k, len(v), f"{avg:.1f}", f"{min(v):.1f}", f"{max(v):.1f}", f"{tf:.0f}" if fl else "", f"{tf / 2516.6:.3f}" if fl else ""])
+    print(open(os.path.join(DST, out_name)).read())
+
+
+per_shape("trace", f"{TAG}_gemm_shapes.csv")
 json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1200])
 for r in rows[:12]:

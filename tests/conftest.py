@@ -9,6 +9,10 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+import leclip_amd  # noqa: E402
+
+leclip_amd.configure()      # the entry points' hardware-queue setting (before any device call): the GPU tests run the product schedule
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

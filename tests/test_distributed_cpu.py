@@ -177,3 +177,83 @@ def test_restart_into_the_same_output_dir_continues(tmp_path):
     tr3 = build_trainer(other)
     tr3.before_train()
     assert tr3.start_epoch == 1
+
+
+# ------------------------------------------------------------------------------ sharded evaluation inside the trainer plug-in
+def _eval_batches():
+    g = torch.Generator().manual_seed(11)
+    batches = []
+    for b, scales in ((5, (4, 9)), (3, (4, 9)), (1, (4, 9)), (4, (4, 9))):
+        img = torch.randn(b, 3, 4, 4, generator=g)
+        lab = (torch.rand(b, 80, generator=g) < 0.1).long()
+        blocks = [torch.randn(b, w, 3, 4, 4, generator=g) for w in scales]
+        batches.append({"img": img, "label": lab, "img_blocks": blocks})
+    return batches
+
+
+def _stub_inference(x, name):   # row-wise deterministic "scores" (global, local): what the batch-invariant HIP path guarantees
+    f = x.flatten(1)
+    base = torch.linspace(0.1, 1.0, 80)[None, :]
+    return torch.sin(f.sum(1, keepdim=True) * base) * 0.6, torch.cos(f[:, :7].sum(1, keepdim=True) * base) * 0.6
+
+
+def _torch_window_aggregate(global_logits, window_logits, threshold=0.3, weight=1.4):   # CDD.py:654-660 (the HIP kernel's arithmetic)
+    alpha, beta = window_logits.max(dim=1)[0], window_logits.min(dim=1)[0]
+    return weight * torch.where(alpha > threshold, alpha, beta) + global_logits
+
+
+def _eval_trainer(with_windows):
+    from leclip_amd.hip import ops
+    from leclip_amd.registry import build_evaluator, build_trainer
+    cfg = _trainer_cfg()
+    cfg.merge_from_list(["DATALOADER.TEST.BATCH_SIZE", "3"])
+    ops.window_aggregate = _torch_window_aggregate          # CPU test of the sharding logic: the aggregation kernel itself is GPU-tested
+    batches = _eval_batches()
+    if not with_windows:
+        for bt in batches:
+            del bt["img_blocks"]
+    tr = build_trainer(cfg, evaluator=build_evaluator(cfg))
+    tr.test_loader = batches
+    tr.model_inference = _stub_inference
+    return tr
+
+
+def _eval_worker(rank, world, port, with_windows, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    parallel.init_from_env(backend="gloo")
+    calls = {"n": 0}
+    real = dist.all_gather
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+    dist.all_gather = counted
+    tr = _eval_trainer(with_windows)
+    calls["n"] = 0
+    value = tr.test()
+    out_q.put((rank, float(value), calls["n"], tr.evaluator.evaluate()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("with_windows", [False, True])
+def test_trainer_test_is_sharded_with_one_collective_per_epoch(with_windows):
+    """Caption_distill_double.test() under WORLD_SIZE = 2 (gloo): every rank scores its shard of each batch's images and of each
+    scale's window list, ONE all-gather per epoch, and every rank's evaluator reports the single-process metric exactly - ragged
+    batches, a batch with fewer images than ranks, global + local scores, sliding-window aggregation."""
+    single = _eval_trainer(with_windows)
+    want = float(single.test())
+    want_all = single.evaluator.evaluate()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_eval_worker, args=(r, 2, port, with_windows, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, value, n_collectives, all_metrics in res:
+        assert n_collectives == 1, (rank, n_collectives)
+        assert value == want and all_metrics == want_all

@@ -115,7 +115,7 @@ def test_gemm_with_fused_layernorm(ops, dt, shape):
     y = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=stats, ln_colsum=cs, out_dtype=torch.float32)
     scale = float(ref.abs().max())
     np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 0, 2.5e-3, 1.5e-2) * scale, rtol=0)
-    part = torch.empty((m, n // 64, 2), dtype=torch.float32, device=DEV)
+    part = torch.empty((n // 64, m, 2), dtype=torch.float32, device=DEV)      # slot-major [N/64][M][2]
     y2 = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=stats, ln_colsum=cs, residual=res.to(DEV), act=o.ACT_QUICKGELU, stats_out=part)
     np.testing.assert_allclose(y2.double().cpu().numpy(), ref_act.numpy(), atol=_tol(dt, 0, 4e-3, 2.5e-2) * float(ref_act.abs().max()), rtol=0)
     st2 = ops.ln_stats_finalize(part, n)
@@ -167,12 +167,13 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
     check(ops.gemm(a, w, bias), ref0 + bias)
     check(ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU), gelu(ref0 + bias))
     check(ops.gemm(a, w, bias, residual=res), ref0 + bias + res.float())
-    part = torch.zeros(M, N // 64, 2, device=DEV)
+    part = torch.zeros(N // 64, M, 2, device=DEV)
     y = ops.gemm_ln(a, w, bias, residual=res, stats_out=part)
     check(y, ref0 + bias + res.float())
     yy = y.float().view(M, N // 64, 64)
-    dev2 = ((yy - yy.mean(-1, keepdim=True)) ** 2).sum(-1)     # partials: (sum, M2 about the block mean) per 64-column block
-    assert float((part[..., 0] - yy.sum(-1)).abs().max()) <= 1e-3 and float((part[..., 1] - dev2).abs().max()) <= 2e-2
+    dev2 = ((yy - yy.mean(-1, keepdim=True)) ** 2).sum(-1)     # partials: (sum, M2 about the block mean) per 64-column block, slot-major
+    pr = part.permute(1, 0, 2)
+    assert float((pr[..., 0] - yy.sum(-1)).abs().max()) <= 1e-3 and float((pr[..., 1] - dev2).abs().max()) <= 2e-2
     check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum), lnref)
     check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=ops.ACT_QUICKGELU), gelu(lnref))
 
@@ -206,10 +207,10 @@ def test_gemm_families_are_bit_identical(ops, dt):
         ]
         for kb, ks in cases:
             assert torch.equal(ops.gemm(a, w, **kb)[lo], ops.gemm(sa, w, **ks))
-        pb, ps = torch.zeros(M, N // 64, 2, device=DEV), torch.zeros(ms, N // 64, 2, device=DEV)
+        pb, ps = torch.zeros(N // 64, M, 2, device=DEV), torch.zeros(N // 64, ms, 2, device=DEV)
         yb = ops.gemm_ln(a, w, bias, residual=res, stats_out=pb)
         ys = ops.gemm_ln(sa, w, bias, residual=sres, stats_out=ps)
-        assert torch.equal(yb[lo], ys) and torch.equal(pb[lo], ps)
+        assert torch.equal(yb[lo], ys) and torch.equal(pb[:, lo], ps)
         for act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
             yb = ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=act)
             ys = ops.gemm_ln(sa, w, bias, ln_stats=sstats, ln_colsum=colsum, act=act)
@@ -838,7 +839,7 @@ def test_fused_layernorm_on_large_mean_rows(ops, dt):
         mu, var = xd.mean(1, keepdim=True), xd.var(1, unbiased=False, keepdim=True)
         # (1) statistics from the producing GEMM's epilogue partials: identity weights make the GEMM output equal its residual input
         eye = torch.zeros(k, k, dtype=dt)
-        part = torch.empty((m, k // 64, 2), dtype=torch.float32, device=DEV)
+        part = torch.empty((k // 64, m, 2), dtype=torch.float32, device=DEV)
         y = ops.gemm_ln(torch.zeros(m, k, dtype=dt, device=DEV), eye.to(DEV), torch.zeros(k, device=DEV), residual=x.to(DEV), stats_out=part)
         assert torch.equal(y.cpu(), x)
         st = ops.ln_stats_finalize(part, k)
