@@ -443,15 +443,24 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
                 }
             }
             float mx = m_run;
+            // only a chunk that reaches past the last valid key needs the per-element mask (wave-uniform test): for the image tower
+            // that is the final chunk alone - two vector instructions per score saved on the others
+            if (a.causal || key0 + 127 > a.T - 1) {
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
+                for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
-                    sc[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                    for (int r = 0; r < 16; ++r) {
+                        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                        const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
+                        sc[kt][r] = v;
+                        mx = fmaxf(mx, v);
+                    }
+            } else {
+#pragma unroll
+                for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+            }
             mx = fmaxf(mx, __shfl_xor(mx, 32));
             const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * a.scale_log2e);   // first chunk: exp2(-huge) = 0
             m_run = mx;

@@ -485,13 +485,18 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         if (DIAG(g.dbg) & 4) t = nk - 2 > 0 ? nk - 2 : 0;
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
         for (; t + 2 < nk; ++t) {
-            // per-phase timeline of K-tiles 4 and 5 of the workgroup's first tile, waves 0 and 4 (the two waves of SIMD 0)
-            const bool on = g.stamps && tile_it == 0 && (t == 4 || t == 5) && (wave == 0 || wave == 4);
-            p.fine = on ? (unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 64 + (t - 4) * 20 : nullptr;
+            // per-phase timeline of EVERY K-tile (up to 12) of the workgroup's SECOND tile - steady state: the previous tile's
+            // epilogue stores and the cross-tile prefetch are in play - waves 0 and 4 (the two waves of SIMD 0)
+            const bool on = g.stamps && tile_it == 1 && t < 12 && (wave == 0 || wave == 4);
+            p.fine = on ? (unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 256 + t * 20 : nullptr;
             p.fine_i = 0;
             p.template ktile<0, EPI_STORES>(t, false, next_src);
         }
-        p.fine = nullptr;
+        {
+            const bool on = g.stamps && tile_it == 1 && t < 12 && (wave == 0 || wave == 4);
+            p.fine = on ? (unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 256 + t * 20 : nullptr;
+            p.fine_i = 0;
+        }
 #else
 #ifdef LECLIP_KLOOP_FR
         for (; t + 2 < nk; ++t) p.template ktile_fr<0, EPI_STORES>(t, false, next_src);
@@ -523,17 +528,27 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                 }
             }
         }
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+        {
+            const bool on = g.stamps && tile_it == 1 && t + 1 < 12 && (wave == 0 || wave == 4);
+            p.fine = on ? (unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 256 + (t + 1) * 20 : nullptr;
+            p.fine_i = 0;
+        }
+#endif
 #ifdef LECLIP_KLOOP_FR
         p.template ktile_fr<2>(t + 1, nx, next_src);
 #else
         p.template ktile<2>(t + 1, nx, next_src);
 #endif
+#if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
+        p.fine = nullptr;
+#endif
         STAMP(1);
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
-        if (g.stamps && tile_it == 0 && (wave == 0 || wave == 4) && lane < 40) {
+        if (g.stamps && tile_it == 1 && (wave == 0 || wave == 4)) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const unsigned* f = (const unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 64;
-            ((unsigned*)(g.stamps + 256 * 16 * 8))[(blockIdx.x * 2 + (wave >> 2)) * 40 + lane] = f[lane];
+            const unsigned* f = (const unsigned*)(smem + 2 * STAGE_BYTES + 8192) + (wave >> 2) * 256;
+            for (int i = lane; i < 240; i += 64) ((unsigned*)(g.stamps + 256 * 16 * 8))[(blockIdx.x * 2 + (wave >> 2)) * 240 + i] = f[i];
         }
 #endif
 

@@ -187,7 +187,7 @@ static void stamps() {
         {2304, 768, 0, false, "qkv"}, {768, 768, 0, true, "out_proj"}, {3072, 768, 1, false, "c_fc+gelu"}, {768, 3072, 0, true, "c_proj"}};
     const int dt = LECLIP_BF16;
     const size_t n_st = 256 * 16 * 8;
-    const size_t n_fine = 256 * 2 * 40;                 // per workgroup, waves 0 / 4: 2 K-tiles x 4 phases x 5 stamps (32-bit)
+    const size_t n_fine = 256 * 2 * 240;                // per workgroup, waves 0 / 4: 12 K-tiles x 4 phases x 5 stamps (32-bit), second tile
     Buf dS(n_st * 8 + n_fine * 4);
     for (auto& s : shapes) {
         auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N);
@@ -227,30 +227,37 @@ static void stamps() {
             printf("  %4d  %5d  %6.0f  %14.0f  %14.0f  %6.0f  %16.0f  %11.0f\n", it, n, seg[0] / n, seg[1] / n, seg[2] / n, seg[3] / n,
                    n_next ? seg[4] / n_next : 0.0, n_next ? seg[5] / n_next : 0.0);
         }
-        {   // per-phase timeline of K-tiles 4-5 (first tile), mean over workgroups, waves 0 and 4 (partners on one SIMD):
+        {   // per-phase timeline of every K-tile of the SECOND tile, mean over workgroups, waves 0 and 4 (partners on one SIMD):
             // segments: mem-cluster-issued -> [wait at barrier 1] -> [lgkmcnt] -> [16 MFMAs issue] -> [wait at barrier 2] -> next phase's memory cluster
             std::vector<unsigned> fs(n_fine);
             HIPCHK(hipMemcpy(fs.data(), (char*)dS.d + n_st * 8, n_fine * 4, hipMemcpyDeviceToHost));
+            const int nkt = s.K / 64 < 12 ? s.K / 64 : 12;
             for (int wv = 0; wv < 2; ++wv) {
-                double seg[8][5] = {};
+                std::vector<double> seg(48 * 6, 0.0);
                 int n = 0;
                 for (int wg = 0; wg < 256; ++wg) {
-                    const unsigned* f = &fs[(size_t)(wg * 2 + wv) * 40];
-                    if (!f[0] || !f[39]) continue;
+                    const unsigned* f = &fs[(size_t)(wg * 2 + wv) * 240];
+                    if (!f[0] || !f[nkt * 20 - 1]) continue;
                     ++n;
-                    for (int ph = 0; ph < 8; ++ph) {
+                    for (int ph = 0; ph < nkt * 4; ++ph) {
                         const unsigned* q = f + ph * 5;
-                        seg[ph][0] += (double)(unsigned)(q[1] - q[0]);      // barrier 1 wait
-                        seg[ph][1] += (double)(unsigned)(q[2] - q[1]);      // lgkmcnt(0)
-                        seg[ph][2] += (double)(unsigned)(q[3] - q[2]);      // MFMA cluster issue
-                        seg[ph][3] += (double)(unsigned)(q[4] - q[3]);      // barrier 2 wait
-                        if (ph < 7) seg[ph][4] += (double)(unsigned)(q[5] - q[4]);   // next memory cluster (reads + DMA issue + vmcnt)
+                        for (int k = 0; k < 4; ++k) seg[ph * 6 + k] += (double)(unsigned)(q[k + 1] - q[k]);
+                        if (ph + 1 < nkt * 4) seg[ph * 6 + 4] += (double)(unsigned)(q[5] - q[4]);
+                        if (ph + 1 < nkt * 4) seg[ph * 6 + 5] += (double)(unsigned)(q[5] - q[0]);
                     }
                 }
                 if (!n) continue;
-                printf("  fine wave %d (n=%d): phase  bar1  lgkm  mfma16  bar2  memcluster(next)\n", wv * 4, n);
-                for (int ph = 0; ph < 8; ++ph)
-                    printf("    kt%d.p%d  %5.0f %5.0f %6.0f %5.0f %6.0f\n", 4 + ph / 4, ph % 4, seg[ph][0] / n, seg[ph][1] / n, seg[ph][2] / n, seg[ph][3] / n, seg[ph][4] / n);
+                printf("  fine wave %d, second tile (n=%d): K-tile  [per phase: bar1 lgkm mfma16 bar2 mem(next)] x4   K-tile total\n", wv * 4, n);
+                for (int kt = 0; kt < nkt; ++kt) {
+                    printf("    kt%-2d", kt);
+                    double tot = 0;
+                    for (int ph = 0; ph < 4; ++ph) {
+                        const double* q = &seg[(kt * 4 + ph) * 6];
+                        printf("  | %4.0f %4.0f %4.0f %4.0f %4.0f", q[0] / n, q[1] / n, q[2] / n, q[3] / n, q[4] / n);
+                        tot += q[5] / n;
+                    }
+                    printf("  | %6.0f\n", tot);
+                }
             }
         }
         // skew between workgroups at the first and the last stamp

@@ -27,7 +27,9 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # LECLIP_DIST_BACKEND=gloo: rehearse the multi-rank path with several ranks on ONE GPU (RCCL refuses two ranks on a device);
+        # recorded by bench.py under env_overrides
+        backend = backend or os.environ.get("LECLIP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -894,3 +894,26 @@ def test_full_batch_forward_is_bit_reproducible(ops):
         assert bool(torch.isfinite(ref).all())
         for _ in range(25):
             assert torch.equal(m.encode_image(img), ref)
+
+
+def test_bench_self_launches_two_ranks_on_one_gpu():
+    """The driver's invocation for N > 1 - a bare `python bench.py --gpus 2 ...` - end to end on this one-GPU box: the script starts its
+    own two ranks under torch.distributed.run (child process, 127.0.0.1), both on cuda:0 with the gloo transport (RCCL refuses two ranks
+    on one device; LECLIP_DIST_BACKEND is recorded in the line), every rank scores its 32 images, the per-rank logits are all-gathered,
+    rank 0 prints ONE JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["LECLIP_DIST_BACKEND"] = "gloo"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "32",
+                          "--no-cpu-baseline", "--no-second-dtype", "--profile-every", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["unit"] == "img/s"
+    assert d["config"]["global_batch"] == 64 and "allgather" in d["config"]["parallelism"] and d["value"] > 0
+    assert "LECLIP_DIST_BACKEND=gloo" in d["env_overrides"]
+    assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 1e-3 * 3)) / d["value"] < 1e-6
