@@ -236,6 +236,13 @@ int leclip_local_pool_bwd(const float* sim, const int64_t* mask_tokens, int64_t 
                           int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale,
                           float logit_scale, void* stream);
 
+/* Caption-feature mixing of the test branch, trainers/Caption_distill_double.py:444-448: sim [B][ld_sim] = normalised global image
+ * features . caption_text_feats^T (columns [0, N)), feats [N][E] the normalised caption features (generate_caption_text_features.py:82-88),
+ * img [B][E] the normalised global image features:  out[b] = (img[b] + mean of the k rows of feats with the largest sim[b]) / 2
+ * (the reference: topk = 10, `.topk(topk, -1)`, `.mean(1)`, `torch.cat([...], 1).mean(1)`).  Ties go to the lower index.  All fp32. */
+int leclip_topk_mix_fwd(const float* sim, const float* feats, const float* img, float* out, int64_t B, int64_t N, int E, int k,
+                        int64_t ld_sim, void* stream);
+
 /* ---- score post-processing of the reference's test loop
  * Sliding-window aggregation, trainers/Caption_distill_double.py:654-660: window_logits [B, W, C] are the scores of the W
  * crops of each image; alpha = max_w, beta = min_w, s_ag = alpha > threshold ? alpha : beta, out = weight * s_ag + global

@@ -89,7 +89,10 @@ def get_cfg_default() -> CfgNode:
         "TEST": {"EVALUATOR": "MLClassification", "EVALUATOR_ACT": "default", "PER_CLASS_RESULT": False,
                  "COMPUTE_CMAT": False, "NO_TEST": False, "SPLIT": "test", "FINAL_MODEL": "last_step",
                  "SAVE_PREDS": "", "multi_model": False, "multi_scale": False, "save_pth": "", "use_freq": False,
-                 "freq_stats": "freq_stats.pkl"},
+                 "freq_stats": "freq_stats.pkl",
+                 # the reference's ./ChatGLM_..._all_caption_text_feats.pkl (Caption_distill_double.py:35-36): a pickled / torch-saved
+                 # [N, E] tensor of normalised caption features for DenseCLIP's top-10 mixing at test time; "" = off
+                 "caption_text_feats": ""},
         "TRAINER": {"NAME": "Caption_distill_double",
                     "Caption": {"N_CTX": 16, "CSC": False, "CTX_INIT": "", "PREC": "fp16",
                                 "CLASS_TOKEN_POSITION": "end", "GL_merge_rate": 0.5, "use_evidence": False}},

@@ -318,6 +318,63 @@ __global__ void cooccurrence_adjust_kernel(const float* __restrict__ p, const fl
     out[i] = p[i] + weight * acc;
 }
 
+// Caption-feature mixing of DenseCLIP's test branch (trainers/Caption_distill_double.py:444-448): per image, the k captions whose
+// (normalised) text features are most similar to the normalised global image feature are averaged, and the global feature becomes the
+// mean of itself and that average:  out[b] = (img[b] + mean_{j in topk(sim[b])} feats[j]) / 2.   sim [B][ld_sim] holds the similarities
+// (exact-fp32 MFMA GEMM by the caller), feats [N][E].  One workgroup per image; the k largest similarities are taken one at a time -
+// pass j finds the largest entry that comes after pass j-1's pick in (value descending, index ascending) order, i.e. torch.topk's set
+// with ties resolved towards the lower index - each pass a strided scan + a block arg-max; k * N reads per image from L2.
+__global__ __launch_bounds__(256) void topk_mix_kernel(const float* __restrict__ sim, const float* __restrict__ feats, const float* __restrict__ img,
+                                                       float* __restrict__ out, int64_t N, int E, int k, int64_t ld_sim) {
+    __shared__ float rv[4];
+    __shared__ int64_t ri[4];
+    __shared__ int64_t pick;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = sim + (int64_t)blockIdx.x * ld_sim;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};      // E <= 1024: feature columns tid, tid + 256, ...
+    float pv = INFINITY;
+    int64_t pi = -1;
+    for (int j = 0; j < k; ++j) {
+        float bv = -INFINITY;
+        int64_t bi = N;
+        for (int64_t i = tid; i < N; i += 256) {
+            const float v = row[i];
+            const bool after = v < pv || (v == pv && i > pi);           // not picked yet
+            if (after && (v > bv || (v == bv && i < bi))) { bv = v; bi = i; }
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ov = __shfl_xor(bv, o);
+            const int64_t oi = __shfl_xor(bi, o);
+            if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { rv[wave] = bv; ri[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            float v = rv[0];
+            int64_t i = ri[0];
+            for (int w = 1; w < 4; ++w) if (rv[w] > v || (rv[w] == v && ri[w] < i)) { v = rv[w]; i = ri[w]; }
+            rv[0] = v;
+            pick = i;
+        }
+        __syncthreads();
+        pv = rv[0];
+        pi = pick;
+        __syncthreads();
+        if (pi < N) {
+            const float* f = feats + pi * E;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const int c = tid + 256 * u; if (c < E) acc[u] += f[c]; }
+        }
+    }
+    const float inv = 1.0f / (float)k;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int c = tid + 256 * u;
+        if (c < E) out[(int64_t)blockIdx.x * E + c] = 0.5f * (img[(int64_t)blockIdx.x * E + c] + acc[u] * inv);
+    }
+}
+
 // ------------------------------------------------------------------------------ embeddings / prompt assembly
 __global__ void embed_tokens_kernel(const int64_t* __restrict__ tokens, const float* __restrict__ table,
                                     const float* __restrict__ pos, void* __restrict__ x, int64_t n_rows, int T, int dim,
@@ -642,6 +699,14 @@ extern "C" int leclip_window_aggregate_fwd(const float* global_logits, const flo
     hipLaunchKernelGGL(window_aggregate_kernel, dim3((unsigned)((B * C + 255) / 256)), dim3(256), 0, (hipStream_t)stream, global_logits,
                        window_logits, out, B, W, C, threshold, weight);
     return leclip_check_launch("window_aggregate_kernel");
+}
+
+extern "C" int leclip_topk_mix_fwd(const float* sim, const float* feats, const float* img, float* out, int64_t B, int64_t N, int E, int k,
+                                   int64_t ld_sim, void* stream) {
+    if (!sim || !feats || !img || !out || B <= 0 || N <= 0 || E <= 0 || k <= 0 || k > N || ld_sim < N) { leclip_set_error("topk_mix: bad argument"); return LECLIP_E_INVALID; }
+    if (E > 1024) { leclip_set_error("topk_mix: E=%d > 1024", E); return LECLIP_E_UNSUPPORTED; }
+    hipLaunchKernelGGL(topk_mix_kernel, dim3((unsigned)B), dim3(256), 0, (hipStream_t)stream, sim, feats, img, out, N, E, k, ld_sim);
+    return leclip_check_launch("topk_mix_kernel");
 }
 
 extern "C" int leclip_cooccurrence_adjust_fwd(const float* p, const float* Mn, float* out, int64_t B, int C, float weight, void* stream) {

@@ -76,6 +76,7 @@ SIGNATURES = {
     "leclip_scatter_rows_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int64, c_int64, c_int, c_void_p]),
     "leclip_l2norm_rows_fwd": (c_int, [c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "leclip_local_pool_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
+    "leclip_topk_mix_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_void_p]),
     "leclip_local_pool_masked_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
     "leclip_local_pool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float,
                                       c_void_p]),

@@ -57,6 +57,20 @@ def load_clip_to_cpu(cfg):
     return clip_pkg.build_model(state_dict)
 
 
+def _load_caption_text_feats(path: str) -> torch.Tensor:
+    """The reference pickles the tensor (`pickle.dump(all_text_feats, f)`, generate_caption_text_features.py:96-97) and reads it back with
+    pickle at import time (:35-36); torch.save files are accepted too."""
+    if not osp.isfile(path):
+        raise FileNotFoundError(f'TEST.caption_text_feats: no file at "{path}"')
+    try:
+        obj = torch.load(path, map_location="cpu")
+    except Exception:
+        import pickle
+        with open(path, "rb") as f:
+            obj = pickle.load(f)
+    return torch.as_tensor(obj).float()
+
+
 class TextEncoder(nn.Module):
     """Reference :72-101.  ``forward(prompts, tokenized_prompts, if_embedding=True, if_sequence=False)``:
     prompts are embeddings [n, T, d] (or token ids when ``if_embedding`` is False); returns fp32 features
@@ -254,7 +268,9 @@ class DenseCLIP(CustomCLIP):
     downstream is the reference's arithmetic (:434-462): normalise, similarities against the "negative" (``ctx_double``)
     prompts, spatial softmax over positions at ``TRAIN.spatial_SCALE_image`` (or ``spatial_T.exp()``), optionally the
     evidence prompts' winner-take-all weighting (``TRAINER.Caption.use_evidence``), ``logits_local = sum_p scale * s * prob``.
-    The top-k caption-feature mixing of :437-440 needs the reference's ChatGLM caption-feature file and is not part of it.
+    The top-10 caption-feature mixing of the global feature (:444-448) is applied when caption features are given
+    (``set_caption_text_feats`` / ``TEST.caption_text_feats``; the reference's own file is not in its repository, ``caption_features``
+    produces the same kind of table from tokenised captions).
     ``if_test=True`` returns (logits_, logits_local, None, None, None) like the reference's test branch; ``if_test=False`` is the
     reference's caption-as-image TRAINING branch (:473-541, ``_forward_captions``), which needs no image tower at all."""
 
@@ -262,6 +278,26 @@ class DenseCLIP(CustomCLIP):
         super().__init__(cfg, classnames, clip_model)
         self.cfg = cfg
         self.prompt_text_features = None
+        # the reference's `caption_text_feats` (:35-36: normalised EOT features of its ~220 k ChatGLM captions, a module-level global
+        # loaded from a pickle that is not in the repository): optional here - set_caption_text_feats() / TEST.caption_text_feats
+        self.caption_text_feats = None
+
+    def set_caption_text_feats(self, feats: Optional[torch.Tensor]):
+        """[N, E] normalised caption features for the test branch's top-10 mixing (:444-448), or None to switch it off."""
+        if feats is not None:
+            dev = self.prompt_learner.ctx.device
+            feats = feats.detach().to(device=dev, dtype=torch.float32).contiguous()
+            if feats.dim() != 2 or feats.shape[0] < 10:
+                raise ValueError("caption_text_feats must be [N >= 10, E]")
+        self.caption_text_feats = feats
+
+    @torch.no_grad()
+    def caption_features(self, captions: torch.Tensor) -> torch.Tensor:
+        """generate_caption_text_features.py:82-88: normalised EOT-row features of tokenised captions [n, 77] (what the reference
+        pickles as caption_text_feats)."""
+        from ..hip import ops
+        captions = captions.to(self.prompt_learner.ctx.device).long().contiguous()
+        return ops.l2norm_rows_(self.text_encoder(captions, None, if_embedding=False, if_sequence=False).float().contiguous().clone())
 
     def _prompt_features(self):
         """text_features / text_features_neg (/ text_features_evidence), cached like the reference (:421-439)."""
@@ -283,6 +319,11 @@ class DenseCLIP(CustomCLIP):
             for i, r in enumerate(rows):
                 w[i * cp:i * cp + c] = r
             feats["w_local"], feats["c_pad"] = w, cp
+            # scale * normalised class prompts, zero-padded: the B operand of the mixed global feature's plain contraction (:449)
+            scale = float(self.prompt_learner.temperature.exp()) if self.cfg.TRAIN.IF_LEARN_SCALE else 4.0
+            wg = torch.zeros((cp, rows[0].shape[1]), dtype=torch.float32, device=rows[0].device)
+            wg[:c] = ops.l2norm_rows_(feats["text_features"].clone()) * scale
+            feats["w_global"] = wg
             self.prompt_text_features = feats
         return self.prompt_text_features
 
@@ -295,7 +336,15 @@ class DenseCLIP(CustomCLIP):
             dense = self.image_encoder.dense_features(image)                 # [B, T, E] fp32
             b, t, e = dense.shape
             logit_scale = float(self.prompt_learner.temperature.exp()) if self.cfg.TRAIN.IF_LEARN_SCALE else 4.0
-            logits_ = ops.l2norm_logits(dense[:, 0].contiguous(), f["text_features"], logit_scale)
+            if self.caption_text_feats is None:
+                logits_ = ops.l2norm_logits(dense[:, 0].contiguous(), f["text_features"], logit_scale)
+            else:
+                # :444-449: the normalised global feature is averaged with the mean of its 10 most similar caption features (NOT
+                # re-normalised), then scored against the normalised class prompts
+                if self.caption_text_feats.shape[1] != e:
+                    raise ValueError(f"caption_text_feats are {self.caption_text_feats.shape[1]}-wide, the model's features {e}")
+                glob = ops.topk_mix(ops.l2norm_rows_(dense[:, 0].contiguous().clone()), self.caption_text_feats, 10)
+                logits_ = ops.gemm(glob, f["w_global"], out_dtype=torch.float32)[:, :f["text_features"].shape[0]].contiguous()
             flat = ops.l2norm_rows_(dense.reshape(b * t, e))                  # image_features / norm (:434), every position
             sim = ops.gemm(flat, f["w_local"], out_dtype=torch.float32)       # exact-fp32 MFMA: [B*T, c_pad (x2)]
             tmp = float(self.prompt_learner.spatial_T.exp()) if self.cfg.TRAIN.IF_LEARN_spatial_SCALE else float(self.cfg.TRAIN.spatial_SCALE_image)
@@ -430,6 +479,9 @@ class Caption_distill_double:
                 sd = torch.load(cfg.MODEL.INIT_WEIGHTS, map_location="cpu")
                 model.prompt_learner.load_state_dict(sd.get("state_dict", sd), strict=False)
             model.to(self.device)
+            feats_path = str(cfg.TEST.get("caption_text_feats", "") or "")
+            if feats_path and isinstance(model, DenseCLIP):
+                model.set_caption_text_feats(_load_caption_text_feats(feats_path))
             self._sync_prompt_learner(model)
             model.eval()
             setattr(self, f"model_{name}", model)

@@ -234,13 +234,32 @@ def local_pool(logits_neg: Tensor, logits_evidence: Optional[Tensor], tmp_scale:
     return torch.sum(logit_scale * logits_neg * prob_spatial, dim=0)
 
 
+def mix_caption_features(image_feature_: Tensor, caption_text_feats: Tensor, topk: int = 10) -> Tensor:
+    """Caption_distill_double.py:444-448: the normalised global feature averaged with the mean of its top-k most similar caption
+    features (the reference hard-codes the RN50 width in `.view(-1, topk, 1024)`; the width in use here).  Pinned:
+    tests/golden/caption_branch.npz mix.* (those reference lines executed by make_golden.py)."""
+    sim_caption = image_feature_ @ caption_text_feats.float().t()
+    _, idx = sim_caption.topk(topk, -1)
+    selected = caption_text_feats[idx.view(-1)].view(-1, topk, caption_text_feats.shape[1]).mean(1)
+    return torch.cat([image_feature_[:, None], selected[:, None]], 1).mean(1)
+
+
+def caption_text_features(captions: Tensor, sd: Dict[str, Tensor]) -> Tensor:
+    """generate_caption_text_features.py:82-88: normalised EOT-row text features of tokenised captions."""
+    return l2_normalize(text_encoder(captions, None, sd, if_embedding=False))
+
+
 def dense_clip_forward(image: Tensor, sd: Dict[str, Tensor], ctx: Tensor, ctx_double: Tensor, ctx_evidence: Optional[Tensor],
-                       prefix: Tensor, suffix: Tensor, tokenized_prompts: Tensor, tmp_scale: float = 40.0, scale: float = 4.0):
-    """DenseCLIP.forward(if_test=True) (:401-462) with the ViT's patch tokens as positions: (logits_, logits_local)."""
+                       prefix: Tensor, suffix: Tensor, tokenized_prompts: Tensor, tmp_scale: float = 40.0, scale: float = 4.0,
+                       caption_text_feats: Optional[Tensor] = None):
+    """DenseCLIP.forward(if_test=True) (:401-462) with the ViT's patch tokens as positions: (logits_, logits_local); with
+    ``caption_text_feats`` the global feature is mixed with its top-10 caption features first (:444-448)."""
     feats = encode_image_tokens(image, sd)                                   # [B, T, E]
     enc = lambda c: l2_normalize(text_encoder(prompt_learner_forward(c, prefix, suffix), tokenized_prompts, sd))
     text, text_neg = enc(ctx), enc(ctx_double)
     glob = l2_normalize(feats[:, 0])
+    if caption_text_feats is not None:
+        glob = mix_caption_features(glob, caption_text_feats)
     pos = l2_normalize(feats[:, 1:]).permute(1, 0, 2)                        # [P, B, E]
     logits_ = scale * glob @ text.t()
     logits_neg = pos @ text_neg.t()

@@ -500,6 +500,19 @@ def caption_branch_goldens(np, torch, synth, build_ref, tokenizer, tokenize, cla
         print("caption branch", tag, "loss", float(loss), "|g ctx|", float(pl.ctx.grad.abs().max()), "|g double|", float(pl.ctx_double.grad.abs().max()),
               "|g evi|", float(np.abs(out[f"{tag}.grad_ctx_evidence"]).max()))
     torch.set_grad_enabled(False)
+    # the test branch's caption-feature mixing (:444-448) on seeded unit vectors.  The lines hard-code the RN50 embedding width
+    # (`.view(-1, topk, 1024)`); the one rewrite is 1024 -> the feature width in use (the reference cannot run them on a ViT as written).
+    mix_src = _dedent_slice(cdd, "topk = 10\n            sim_caption = (image_feature_ @ caption_text_feats.float().t())",
+                            "image_feature_ = torch.cat([image_feature_[:, None], selected_caption_text_feats[:, None]], 1).mean(1)", True)
+    e_dim = 64
+    unit = lambda t: t / t.norm(dim=-1, keepdim=True)
+    img_f = unit(torch.from_numpy(synth.normal(21, "mix.img", (7, e_dim))))
+    cap_f = unit(torch.from_numpy(synth.normal(22, "mix.cap", (333, e_dim))) + 0.4 * img_f[:1])
+    cap_f[5] = cap_f[3]                                   # an exact tie inside the candidate set
+    ns_x = {"torch": torch, "image_feature_": img_f.clone(), "caption_text_feats": cap_f}
+    exec(mix_src.replace("1024", str(e_dim)), ns_x)
+    out.update({"mix.image_feature": img_f.numpy(), "mix.caption_text_feats": cap_f.numpy(), "mix.mixed": ns_x["image_feature_"].numpy(),
+                "mix.topk_scores": ns_x["topk_sim_caption_scores"].numpy()})
     np.savez_compressed(os.path.join(OUT, "caption_branch.npz"), **out)
 
 

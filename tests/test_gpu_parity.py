@@ -917,3 +917,51 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert d["config"]["global_batch"] == 64 and "allgather" in d["config"]["parallelism"] and d["value"] > 0
     assert "LECLIP_DIST_BACKEND=gloo" in d["env_overrides"]
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 1e-3 * 3)) / d["value"] < 1e-6
+
+
+def test_caption_feature_mixing_kernel(ops, golden_dir):
+    """leclip_topk_mix_fwd (exact-fp32 similarity GEMM + native top-10 / mean / average) against the reference's own lines :444-448
+    (tests/golden/caption_branch.npz mix.*), incl. an exact tie in the candidate set and a table that is not a multiple of 64 rows."""
+    g = np.load(os.path.join(golden_dir, "caption_branch.npz"))
+    img, cap = torch.from_numpy(g["mix.image_feature"]).to(DEV), torch.from_numpy(g["mix.caption_text_feats"]).to(DEV)
+    got = ops.topk_mix(img, cap, 10)
+    np.testing.assert_allclose(got.cpu().numpy(), g["mix.mixed"], atol=2e-6, rtol=0)
+    ref1 = torch.from_numpy(g["mix.image_feature"])
+    sim = ref1 @ torch.from_numpy(g["mix.caption_text_feats"]).t()
+    want = 0.5 * (ref1 + torch.from_numpy(g["mix.caption_text_feats"])[sim.topk(1, -1).indices[:, 0]])
+    np.testing.assert_allclose(ops.topk_mix(img, cap, 1).cpu().numpy(), want.numpy(), atol=2e-6, rtol=0)
+
+
+def test_dense_clip_with_caption_features(ops, golden_dir):
+    """DenseCLIP test branch with the reference's caption-feature mixing switched on (TEST.caption_text_feats / set_caption_text_feats):
+    the table comes from the model's own caption_features() (generate_caption_text_features.py:82-88), scores against the oracle."""
+    from leclip_amd.clip import build_model
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import DenseCLIP
+    from oracle import clip_oracle as co
+    arch = synth.TINY
+    sd = synth.make_state_dict(arch, seed=1, dist="cond")
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+    model = DenseCLIP(cfg, coco_object_categories, build_model(sd).float()).to(DEV).eval()
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    caps = torch.from_numpy(t["tokens_photo"])
+    table = model.caption_features(caps)
+    ref_table = co.caption_text_features(caps, sd)
+    np.testing.assert_allclose(table.cpu().numpy(), ref_table.numpy(), atol=2e-5, rtol=0)
+    model.set_caption_text_feats(ref_table)
+    img = torch.from_numpy(synth.make_images(5, arch.image_resolution, seed=3))
+    with torch.no_grad():
+        logits_, logits_local, _, _, _ = model(img.to(DEV), if_test=True)
+    toks = torch.from_numpy(t["tokens_ctx16"])
+    prefix, suffix = co.prompt_buffers(toks, sd, 16)
+    pl = model.prompt_learner
+    ref, ref_local = co.dense_clip_forward(img, sd, pl.ctx.detach().cpu(), pl.ctx_double.detach().cpu(), None, prefix, suffix, toks, 40.0, 4.0,
+                                           caption_text_feats=ref_table)
+    np.testing.assert_allclose(logits_.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=0)
+    np.testing.assert_allclose(logits_local.cpu().numpy(), ref_local.numpy(), atol=2e-4, rtol=1e-4)
+    model.set_caption_text_feats(None)
+    with torch.no_grad():
+        plain = model(img.to(DEV), if_test=True)[0]
+    assert float((plain - logits_).abs().max()) > 1e-3          # the mixing does change the global scores

@@ -197,3 +197,11 @@ def test_caption_training_branch_and_its_gradients(golden_dir, tag):
         got = c.grad.numpy() if c.grad is not None else np.zeros_like(want)
         scale = max(float(np.abs(want).max()), 1e-6)
         assert float(np.abs(got - want).max()) <= 2e-4 * scale, name
+
+
+def test_caption_feature_mixing(golden_dir):
+    """oracle.mix_caption_features against Caption_distill_double.py:444-448 executed by make_golden.py (top-10 of the caption
+    similarities, their mean, averaged with the global feature; a tie inside the candidate set)."""
+    g = np.load(os.path.join(golden_dir, "caption_branch.npz"))
+    got = co.mix_caption_features(torch.from_numpy(g["mix.image_feature"]), torch.from_numpy(g["mix.caption_text_feats"]), 10)
+    np.testing.assert_allclose(got.numpy(), g["mix.mixed"], atol=1e-7, rtol=0)
