@@ -872,7 +872,11 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
 #else
     constexpr int cap = 0, force_generic = 0;
 #endif
+#ifdef LECLIP_GEMM_GRID_MULT      // A/B builds: grid = LECLIP_GEMM_GRID_MULT x CUs (hardware hands the surplus workgroups to CUs as they free up)
+    const int limit = cap > 0 ? cap : n_cu * LECLIP_GEMM_GRID_MULT;
+#else
     const int limit = cap > 0 ? cap : n_cu;
+#endif
     const int grid = a.tiles_total < limit ? a.tiles_total : limit;   // one persistent workgroup per CU (160 KiB LDS each)
     const EpiParams& e = a.epi;
     const int tdt = sizeof(T) == 2 && __is_same(T, bf16_t) ? LECLIP_BF16 : LECLIP_F16;

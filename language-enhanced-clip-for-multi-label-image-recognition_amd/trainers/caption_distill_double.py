@@ -831,16 +831,22 @@ class Caption_distill_double:
             input, label, input_blocks = self.parse_batch_test(batch)
             b = input.shape[0]
             lo, hi = parallel.shard_bounds(b, self.rank, self.world)
-            res = self.model_inference(input[lo:hi].contiguous(), name)
-            out = res[0].float()
-            pos = res[1].float() if res[1] is not None else None
-            n_cls = out.shape[1]
-            if use_freq and pos is not None:
-                pos = ops.cooccurrence_adjust(pos, self.cooccurrence_matrix(), 0.5) if pos.shape[0] else pos
+            model = getattr(self, f"model_{name}", None)
+            n_cls = model.prompt_learner.n_cls if model is not None else len(self.classnames)
+            out = pos = None
+            if hi > lo:      # (more ranks than images in this batch: nothing of it is this rank's)
+                res = self.model_inference(input[lo:hi].contiguous(), name)
+                out = res[0].float()
+                pos = res[1].float() if res[1] is not None else None
+                n_cls = out.shape[1]
+                if use_freq and pos is not None:
+                    pos = ops.cooccurrence_adjust(pos, self.cooccurrence_matrix(), 0.5)
             cols = [torch.full((b, n_cls), ninf, dtype=torch.float32, device=dev) for _ in range(6)]
-            cols[0][lo:hi] = out
-            if pos is not None:
+            if out is not None:
+                cols[0][lo:hi] = out
+            if pos is not None or isinstance(model, DenseCLIP):
                 has_pos = True
+            if pos is not None:
                 cols[1][lo:hi] = pos
             if mode == "test" and input_blocks is not None:
                 has_win = True
