@@ -72,6 +72,10 @@ def main():
     ap.add_argument("--mode", default="score", choices=["score", "tune"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
+    ap.add_argument("--tune-model", default="CustomCLIP", choices=["CustomCLIP", "DenseCLIP"],
+                    help="--mode tune: CustomCLIP = image batches through the frozen image tower, BCE (BASELINE configs[2] as worded); DenseCLIP = the "
+                         "step the reference's shipped configs run: tokenised captions as images, global + local head, three prompt sets, "
+                         "double_ranking + EMA distillation loss (value = captions/s)")
     ap.add_argument("--dry-launch", action="store_true", help="with --gpus N > 1 and no torchrun environment: print the launcher "
                     "command this invocation would start (one JSON line) and exit without starting it")
     args = ap.parse_args()
@@ -328,14 +332,26 @@ def tune(args):
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE={world}")
     B = args.batch if args.batch != 256 else 512
     cfg = get_cfg_default()
+    dense = args.tune_model == "DenseCLIP"
     cfg.merge_from_list(["MODEL.BACKBONE.NAME", args.arch, "MODEL.BACKBONE.PATH", "synthetic:0:cond", "TRAINER.Caption.PREC",
-                         args.dtype, "TRAIN.LOSSFUNC", "bce", "OPTIM.WARMUP_EPOCH", "0"])
+                         args.dtype, "TRAIN.LOSSFUNC", "double_ranking" if dense else "bce", "OPTIM.WARMUP_EPOCH", "0"]
+                        + (["TRAIN.MODEL", "DenseCLIP", "TRAINER.Caption.use_evidence", "True", "TRAIN.ema", "True"] if dense else []))
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):     # the trainer announces itself on stdout like the reference; stdout carries ONE JSON line
         tr = build_trainer(cfg)
     arch = synth.ARCHS[args.arch]
-    images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(tr.device)
     labels = torch.from_numpy((synth.uniform(3 + rank, "tune.labels", (B, 80), 0, 1) < 0.04).astype("float32")).to(tr.device)
+    if dense:      # captions: the cached class prompts, cycled (the offline image has no merge table for free text); labels = their classes
+        from leclip_amd.clip import tokenize
+        from leclip_amd.datasets import coco_object_categories
+        base = tokenize([f"a photo of a {c.replace('_', ' ')}." for c in coco_object_categories])
+        pick = (torch.arange(B) * 7 + 13 * rank) % 80
+        images = base[pick].contiguous().to(tr.device)
+        labels = torch.zeros(B, 80)
+        labels[torch.arange(B), pick] = 1.0
+        labels = labels.to(tr.device)
+    else:
+        images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(tr.device)
     batch = {"img": images, "label": labels}
 
     def fence():
@@ -357,11 +373,16 @@ def tune(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     if rank == 0:
-        print(json.dumps({"metric": f"images/sec (prompt-tuning step, {args.arch} frozen image tower + text tower fwd/bwd w.r.t. 16 ctx, B={B}/GPU)",
-                          "value": world * B * args.steps / dt, "unit": "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        what = (f"captions/sec (DenseCLIP caption-as-image tuning step, {args.arch} text tower: {B} captions fwd + 240 prompts fwd/bwd w.r.t. 3 x 16 ctx, "
+                f"global + local head, double_ranking + EMA distillation, B={B}/GPU)") if dense else \
+               f"images/sec (prompt-tuning step, {args.arch} frozen image tower + text tower fwd/bwd w.r.t. 16 ctx, B={B}/GPU)"
+        print(json.dumps({"metric": what,
+                          "value": world * B * args.steps / dt, "unit": "captions/s" if dense else "img/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                           "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                           "dtype": args.dtype, "data": "synthetic",
-                          "config": {"workload": f"BASELINE configs[2]: {args.arch}, 16 learnable context tokens, B={B}/GPU, BCE, SGD",
+                          "config": {"workload": (f"reference's shipped tuning step (TRAIN.MODEL=DenseCLIP): {args.arch}, 3 x 16 learnable context tokens, B={B} captions/GPU, "
+                                                  f"double_ranking + EMA KL, SGD") if dense else
+                                                 f"BASELINE configs[2]: {args.arch}, 16 learnable context tokens, B={B}/GPU, BCE, SGD",
                                      "global_batch": world * B, "parallelism": f"dp{world}" + ("+allreduce(ctx grads)" if world > 1 else "")},
                           "last_loss": out["loss"], "env_overrides": overrides}))
     if world > 1:

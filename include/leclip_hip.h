@@ -231,10 +231,18 @@ int leclip_local_pool_masked_fwd(const float* sim, const int64_t* mask_tokens, i
 /* Gradient of that pooling w.r.t. the similarity panels (the `ranking_loss(output_local, ...)` term of :806-808 on its way to
  * ctx_double / ctx_evidence): dout [B, C] -> dneg [B*P, C] (d / d s) and, with evidence, devi [B*P, C] (d / d e), contiguous.
  * torch's max(-1) in the winner-take-all weight (:509) hands its gradient to the arg-max class; so does this.  The panels of one
- * image must fit LDS (P * C * 12 bytes with evidence): the training branch pools 77 positions. */
+ * image must fit LDS (P * C * 12 bytes with evidence): the training branch pools 77 positions.
+ * transposed_ld > 0: dneg / devi are written TRANSPOSED, [C][transposed_ld] with element (c, b * P + p) (transposed_ld >= B * P; pad
+ * columns are not touched): the K-contiguous operand of the GEMM that contracts them with the position features (below). */
 int leclip_local_pool_bwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, const float* dout, float* dneg, float* devi,
                           int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale,
-                          float logit_scale, void* stream);
+                          float logit_scale, int64_t transposed_ld, void* stream);
+/* Pieces of the similarity GEMM's backward w.r.t. the text features (sim = normalise(positions) . normalise(text)^T, :495, :503):
+ * dst [cols][ld_dst] = src [rows][ld_src]^T (fp32), and the backward of the row normalisation, dx = (dy - x_hat <x_hat, dy>) / |x|.
+ * d text = l2norm_rows_bwd(text, gemm(dsim^T, positions_hat^T)): one exact-fp32 MFMA GEMM over all B * 77 rows instead of 80 workgroups
+ * each streaming the whole position matrix. */
+int leclip_transpose_f32_fwd(const float* src, float* dst, int64_t rows, int cols, int64_t ld_src, int64_t ld_dst, void* stream);
+int leclip_l2norm_rows_bwd(const float* x, const float* dy, float* dx, int64_t rows, int dim, void* stream);
 
 /* Caption-feature mixing of the test branch, trainers/Caption_distill_double.py:444-448: sim [B][ld_sim] = normalised global image
  * features . caption_text_feats^T (columns [0, N)), feats [N][E] the normalised caption features (generate_caption_text_features.py:82-88),

@@ -315,6 +315,45 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x,
     for (int k = lane * 4; k < dim; k += 256) { f32x4 t = *(const f32x4*)(xr + k); t[0] *= inv; t[1] *= inv; t[2] *= inv; t[3] *= inv; *(f32x4*)(xr + k) = t; }
 }
 
+// dst [cols][ld_dst] = src [rows][ld_src]^T (fp32, 32 x 32 tiles through LDS): the K-contiguous form of the position features for the
+// contraction over positions in the local branch's backward.
+__global__ __launch_bounds__(256) void transpose_f32_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int cols,
+                                                            int64_t ld_src, int64_t ld_dst) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    const int64_t r0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t r = r0 + ty + 8 * k;
+        tile[ty + 8 * k][tx] = (r < rows && c0 + tx < cols) ? src[r * ld_src + c0 + tx] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k;
+        const int64_t r = r0 + tx;
+        if (c < cols && r < rows) dst[(int64_t)c * ld_dst + r] = tile[tx][ty + 8 * k];
+    }
+}
+
+// Backward of y = x / |x| per row (fp32): dx = (dy - yhat <yhat, dy>) / |x|, one wave per row - from the gradient w.r.t. the
+// NORMALISED text features (what the similarity GEMM's backward yields) to the gradient w.r.t. the text tower's output.
+__global__ __launch_bounds__(256) void l2norm_rows_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                              int64_t rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const float* xr = x + r * dim;
+    const float* gr = dy + r * dim;
+    float xx = 0.f, xg = 0.f;
+    for (int k = lane; k < dim; k += 64) { xx = fmaf(xr[k], xr[k], xx); xg = fmaf(xr[k], gr[k], xg); }
+    xx = wave_sum(xx);
+    xg = wave_sum(xg);
+    const float nrm = sqrtf(xx);
+    for (int k = lane; k < dim; k += 64) dx[r * dim + k] = (gr[k] - xr[k] * (xg / xx)) / nrm;
+}
+
 // Local (dense) branch pooling, trainers/Caption_distill_double.py:447-462 (image branch: patches in place of the ResNet's HxW
 // positions) and :493-513 (caption-as-image training branch: the 77 token positions, `text_mask` added to both panels):
 //   s[p, c]  = <position feature p, "negative" prompt c> (both normalised) + bias[p], e[p, c] the same against the evidence prompts,
@@ -390,9 +429,12 @@ __global__ __launch_bounds__(256) void local_pool_kernel(const float* __restrict
 //                 per position, with H = sum_c g s w, u_c = w_c (g_c s_c - H):  ds_c = g_c w_c + k u_c + [c == argmax_c s] tmp sum_c' u_c' s_c'
 //                 (k = tmp (max_c s + 1) depends on s through its maximum: torch's max(-1) hands that gradient to the arg-max element)
 // One workgroup per image, whole panels in LDS (positions x classes x 12 bytes: the caption branch is 77 x 80).
+// t_ld > 0: the outputs are written TRANSPOSED, dneg / devi [C][t_ld] with element (c, b * P + p) - the K-contiguous A operand of the
+// GEMM that contracts them with the position features over all B * P rows (d text features = dsim^T . features).
 __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __restrict__ sim, const int64_t* __restrict__ mask_tok, const float* __restrict__ dout,
                                                              float* __restrict__ dneg, float* __restrict__ devi, int P, int C, int64_t ld,
-                                                             int64_t image_stride, int64_t mask_stride, int evi_off, float tmp, float logit_scale) {
+                                                             int64_t image_stride, int64_t mask_stride, int evi_off, float tmp, float logit_scale,
+                                                             int64_t t_ld) {
     extern __shared__ float sm[];      // k[P] | s_ext[P] | den[P] | bias[P] | amax[P] | cmx[C] | cden[C] | cm[C] | s [P][C] | g [P][C] (| e [P][C])
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* src = sim + (int64_t)blockIdx.x * image_stride;
@@ -446,17 +488,22 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
     }
     __syncthreads();
     const float* dob = dout + (int64_t)blockIdx.x * C;
-    float* dn = dneg + (int64_t)blockIdx.x * P * C;
-    float* de = devi ? devi + (int64_t)blockIdx.x * P * C : nullptr;
-    for (int i = tid; i < P * C; i += 256) {
-        const int p = i / C, c = i - p * C;
+    const int64_t row0 = (int64_t)blockIdx.x * P;
+    // element (p, c) of this image's block: row-major [rows][C], or transposed [C][t_ld]
+    auto at = [&](float* base_, int p, int c) -> float& { return t_ld > 0 ? base_[(int64_t)c * t_ld + row0 + p] : base_[(row0 + p) * C + c]; };
+    float* dn = dneg;
+    float* de = devi;
+    for (int j = tid; j < P * C; j += 256) {
+        // transposed output: consecutive threads take consecutive positions of one class (contiguous stores)
+        const int p = t_ld > 0 ? j % P : j / C, c = t_ld > 0 ? j / P : j - (j / C) * C;
+        const int i = p * C + c;
         const float prob = expf(tmp * z[i] - cmx[c]) / cden[c];
         const float gs = dob[c] * logit_scale * prob;
         if (!evi) {
-            dn[i] = gs * (1.0f + tmp * (s[i] - cm[c]));
+            at(dn, p, c) = gs * (1.0f + tmp * (s[i] - cm[c]));
         } else {
             const float sv = s[i] * (expf(rk[p] * (s[i] - rz[p])) / rd[p]);
-            de[i] = gs * tmp * (sv - cm[c]);
+            at(de, p, c) = gs * tmp * (sv - cm[c]);
             g[i] = gs;
         }
     }
@@ -479,7 +526,7 @@ __global__ __launch_bounds__(256) void local_pool_bwd_kernel(const float* __rest
         for (int c = lane; c < C; c += 64) {
             const float w = expf(k * (row[c] - zm)) / dnm;
             const float u = w * (gr[c] * row[c] - H);
-            dn[p * C + c] = fmaf(k, u, gr[c] * w) + (c == am ? tmp * S : 0.0f);
+            at(dn, p, c) = fmaf(k, u, gr[c] * w) + (c == am ? tmp * S : 0.0f);
         }
     }
 }
@@ -570,6 +617,19 @@ extern "C" int leclip_l2norm_rows_fwd(float* x, int64_t rows, int dim, int64_t l
     return leclip_check_launch("l2norm_rows_kernel");
 }
 
+extern "C" int leclip_transpose_f32_fwd(const float* src, float* dst, int64_t rows, int cols, int64_t ld_src, int64_t ld_dst, void* stream) {
+    if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < rows) { leclip_set_error("transpose_f32: bad argument"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(transpose_f32_kernel, dim3((unsigned)((rows + 31) / 32), (unsigned)((cols + 31) / 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows,
+                       cols, ld_src, ld_dst);
+    return leclip_check_launch("transpose_f32_kernel");
+}
+
+extern "C" int leclip_l2norm_rows_bwd(const float* x, const float* dy, float* dx, int64_t rows, int dim, void* stream) {
+    if (!x || !dy || !dx || rows <= 0 || dim <= 0) { leclip_set_error("l2norm_rows_bwd: bad argument"); return LECLIP_E_INVALID; }
+    hipLaunchKernelGGL(l2norm_rows_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, rows, dim);
+    return leclip_check_launch("l2norm_rows_bwd_kernel");
+}
+
 static int local_pool_args_ok(const float* sim, int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, const int64_t* mask_tokens,
                               int64_t mask_stride) {
     return sim && B > 0 && P > 0 && C > 0 && ld >= C && image_stride >= (int64_t)(P - 1) * ld + C && !(evidence_offset >= 0 && evidence_offset + C > ld) &&
@@ -603,8 +663,9 @@ extern "C" int leclip_local_pool_masked_fwd(const float* sim, const int64_t* mas
 
 extern "C" int leclip_local_pool_bwd(const float* sim, const int64_t* mask_tokens, int64_t mask_stride, const float* dout, float* dneg, float* devi,
                                      int64_t B, int P, int C, int64_t ld, int64_t image_stride, int evidence_offset, float spatial_scale, float logit_scale,
-                                     void* stream) {
-    if (!dout || !dneg || (evidence_offset >= 0) != (devi != nullptr) || !local_pool_args_ok(sim, B, P, C, ld, image_stride, evidence_offset, mask_tokens, mask_stride)) {
+                                     int64_t transposed_ld, void* stream) {
+    if (!dout || !dneg || (evidence_offset >= 0) != (devi != nullptr) || (transposed_ld != 0 && transposed_ld < B * P) ||
+        !local_pool_args_ok(sim, B, P, C, ld, image_stride, evidence_offset, mask_tokens, mask_stride)) {
         leclip_set_error("local_pool_bwd: null pointer or inconsistent sizes");
         return LECLIP_E_INVALID;
     }
@@ -613,6 +674,6 @@ extern "C" int leclip_local_pool_bwd(const float* sim, const int64_t* mask_token
     static bool attr_set[LECLIP_MAX_DEVICES] = {};
     leclip_set_max_lds(local_pool_bwd_kernel, 160 * 1024, attr_set);
     hipLaunchKernelGGL(local_pool_bwd_kernel, dim3((unsigned)B), dim3(256), lds, (hipStream_t)stream, sim, mask_tokens, dout, dneg, devi, P, C, ld, image_stride,
-                       mask_stride, evidence_offset, spatial_scale, logit_scale);
+                       mask_stride, evidence_offset, spatial_scale, logit_scale, transposed_ld);
     return leclip_check_launch("local_pool_bwd_kernel");
 }

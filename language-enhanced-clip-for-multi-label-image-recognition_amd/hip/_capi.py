@@ -79,7 +79,9 @@ SIGNATURES = {
     "leclip_topk_mix_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int64, c_void_p]),
     "leclip_local_pool_masked_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float, c_void_p]),
     "leclip_local_pool_bwd": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int, c_float, c_float,
-                                      c_void_p]),
+                                      c_int64, c_void_p]),
+    "leclip_transpose_f32_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_void_p]),
+    "leclip_l2norm_rows_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
     "leclip_bpe_open": (c_void_p, [c_char_p]),
     "leclip_bpe_close": (None, [c_void_p]),
     "leclip_bpe_vocab_size": (c_int64, [c_void_p]),

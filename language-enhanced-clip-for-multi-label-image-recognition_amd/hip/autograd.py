@@ -125,29 +125,32 @@ class LocalPoolFunction(torch.autograd.Function):
         flat = seq.detach().float().contiguous().view(b * t, e)
         tn = txt_neg.detach().float().contiguous()
         te = txt_evi.detach().float().contiguous() if txt_evi is not None else None
-        sim, c_pad = local_similarity(flat, tn, te)
+        sim, c_pad, fhat = local_similarity(flat, tn, te)
         c = tn.shape[0]
         evi = c_pad if te is not None else -1
         toks = tokens.to(device=seq.device, dtype=torch.int64).contiguous()
         out = ops.local_pool(sim, b, t, 0, c, evi, spatial_scale, logit_scale, mask_tokens=toks)
-        ctx.save_for_backward(flat, tn, te if te is not None else tn, sim, toks)
-        ctx.meta = (b, t, c, evi, float(spatial_scale), float(logit_scale), te is not None)
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(fhat, tn, te if te is not None else tn, sim, toks)
+            ctx.meta = (b, t, c, evi, float(spatial_scale), float(logit_scale), te is not None)
         return out
 
     @staticmethod
     def backward(ctx, dout: torch.Tensor):
-        flat, tn, te, sim, toks = ctx.saved_tensors
+        fhat, tn, te, sim, toks = ctx.saved_tensors
         b, t, c, evi, spatial_scale, logit_scale, has_evi = ctx.meta
-        dneg, devi = ops.local_pool_bwd(sim, dout.float().contiguous(), b, t, 0, c, evi, spatial_scale, logit_scale, mask_tokens=toks)
-        d_tn = ops.l2norm_logits_bwd(flat, tn, dneg, 1.0)
-        d_te = ops.l2norm_logits_bwd(flat, te, devi, 1.0) if has_evi else None
+        dneg_t, devi_t = ops.local_pool_bwd(sim, dout.float().contiguous(), b, t, 0, c, evi, spatial_scale, logit_scale, mask_tokens=toks,
+                                            transposed=True)                       # [C, rows_pad]
+        fhat_t = ops.transpose_f32(fhat)                                           # [E, rows_pad]
+        d_tn = ops.l2norm_rows_bwd(tn, ops.gemm(dneg_t, fhat_t, out_dtype=torch.float32))
+        d_te = ops.l2norm_rows_bwd(te, ops.gemm(devi_t, fhat_t, out_dtype=torch.float32)) if has_evi else None
         return None, d_tn, d_te, None, None, None
 
 
 def local_similarity(flat: torch.Tensor, txt_neg: torch.Tensor, txt_evi=None):
     """[rows, c_pad (x2)] fp32 cosine similarities of every (unnormalised) feature row against the negative (| evidence) prompt
     features: rows and prompts normalised by the row-norm kernel, contraction on the exact-fp32 MFMA GEMM; the prompt panel is
-    zero-padded to 64-row blocks (the GEMM's N granularity).  Returns (sim, c_pad)."""
+    zero-padded to 64-row blocks (the GEMM's N granularity).  Returns (sim, c_pad, normalised rows)."""
     rows = [ops.l2norm_rows_(txt_neg.clone())]
     if txt_evi is not None:
         rows.append(ops.l2norm_rows_(txt_evi.clone()))
@@ -157,4 +160,4 @@ def local_similarity(flat: torch.Tensor, txt_neg: torch.Tensor, txt_evi=None):
     for i, r in enumerate(rows):
         w[i * cp:i * cp + c] = r
     fhat = ops.l2norm_rows_(flat.clone())
-    return ops.gemm(fhat, w, out_dtype=torch.float32), cp
+    return ops.gemm(fhat, w, out_dtype=torch.float32), cp, fhat

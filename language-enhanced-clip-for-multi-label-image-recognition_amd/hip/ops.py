@@ -554,8 +554,9 @@ def _mask_arg(mask_tokens, batch, tokens, first, device):
 
 
 def local_pool_bwd(sim: torch.Tensor, dout: torch.Tensor, batch: int, tokens: int, first: int, n_cls: int, evidence_offset: int,
-                   spatial_scale: float, logit_scale: float, mask_tokens: Optional[torch.Tensor] = None):
-    """Gradient of ``local_pool`` w.r.t. the two similarity panels: (dneg, devi or None), each [batch * (tokens - first), n_cls] fp32."""
+                   spatial_scale: float, logit_scale: float, mask_tokens: Optional[torch.Tensor] = None, transposed: bool = False):
+    """Gradient of ``local_pool`` w.r.t. the two similarity panels: (dneg, devi or None), each [batch * (tokens - first), n_cls] fp32 -
+    or, ``transposed``, [n_cls, rows padded to a multiple of 32] with zero pad columns (the K-contiguous GEMM operand)."""
     _dev(sim, "sim")
     _dev(dout, "dout")
     assert sim.dtype == torch.float32 and sim.is_contiguous() and sim.shape[0] == batch * tokens
@@ -563,9 +564,40 @@ def local_pool_bwd(sim: torch.Tensor, dout: torch.Tensor, batch: int, tokens: in
         raise TypeError("local_pool_bwd: dout must be contiguous float32 [batch, n_cls]")
     ld = sim.shape[1]
     p = tokens - first
-    dneg = torch.empty((batch * p, n_cls), dtype=torch.float32, device=sim.device)
-    devi = torch.empty_like(dneg) if evidence_offset >= 0 else None
+    rows = batch * p
+    if transposed:
+        t_ld = (rows + 31) // 32 * 32
+        make = lambda: (torch.zeros if t_ld != rows else torch.empty)((n_cls, t_ld), dtype=torch.float32, device=sim.device)
+    else:
+        t_ld = 0
+        make = lambda: torch.empty((rows, n_cls), dtype=torch.float32, device=sim.device)
+    dneg = make()
+    devi = make() if evidence_offset >= 0 else None
     mask = _mask_arg(mask_tokens, batch, tokens, first, sim.device)
     _capi.check(_capi.load().leclip_local_pool_bwd(_ptr(sim[first:]), _ptr(mask), tokens, _ptr(dout), _ptr(dneg), _ptr(devi), batch, p, n_cls, ld, tokens * ld,
-                                                   evidence_offset, float(spatial_scale), float(logit_scale), _stream()), "local_pool_bwd")
+                                                   evidence_offset, float(spatial_scale), float(logit_scale), t_ld, _stream()), "local_pool_bwd")
     return dneg, devi
+
+
+def transpose_f32(src: torch.Tensor, pad_cols_to: int = 32) -> torch.Tensor:
+    """[cols, rows padded to a multiple of ``pad_cols_to``] = src^T for a contiguous fp32 [rows, cols] matrix (pad columns zero)."""
+    _dev(src, "src")
+    if src.dtype != torch.float32 or src.dim() != 2 or not src.is_contiguous():
+        raise TypeError("transpose_f32: contiguous float32 [rows, cols] expected")
+    rows, cols = src.shape
+    ld = (rows + pad_cols_to - 1) // pad_cols_to * pad_cols_to
+    dst = (torch.zeros if ld != rows else torch.empty)((cols, ld), dtype=torch.float32, device=src.device)
+    _capi.check(_capi.load().leclip_transpose_f32_fwd(_ptr(src), _ptr(dst), rows, cols, cols, ld, _stream()), "transpose_f32")
+    return dst
+
+
+def l2norm_rows_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """Backward of the row normalisation y = x / |x|: dx = (dy - y <y, dy>) / |x| (fp32 [rows, dim], contiguous)."""
+    for name, t in (("x", x), ("dy", dy)):
+        _dev(t, name)
+        if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() != 2:
+            raise TypeError(f"l2norm_rows_bwd: {name} must be contiguous float32 [rows, dim]")
+    assert x.shape == dy.shape
+    dx = torch.empty_like(x)
+    _capi.check(_capi.load().leclip_l2norm_rows_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.shape[0], x.shape[1], _stream()), "l2norm_rows_bwd")
+    return dx

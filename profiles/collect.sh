@@ -35,7 +35,11 @@ timeout -k 10 400 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format
 echo vitl done
 TUNE="python3 $R/bench.py --mode tune --dtype bf16 --steps 4 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tune -- $TUNE > $OUT/tune.log 2>&1 || exit 1
+# the reference's shipped tuning step (TRAIN.MODEL = DenseCLIP): captions as images, global + local head, three prompt sets, EMA loss
+DENSE="python3 $R/bench.py --mode tune --tune-model DenseCLIP --dtype fp16 --steps 4 --warmup 2"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tune_dense -- $DENSE > $OUT/tune_dense.log 2>&1 || exit 1
 cd $R
+timeout -k 10 300 python3 bench.py --mode tune --tune-model DenseCLIP --dtype fp16 --steps 10 --warmup 3 > $OUT/tune_dense_bench.json 2> $OUT/tune_dense_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --arch ViT-L/14@336px --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --no-second-dtype > $OUT/vitl_bench.json 2> $OUT/vitl_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --mode tune --dtype bf16 --steps 10 --warmup 3 > $OUT/tune_bench.json 2> $OUT/tune_bench.err || exit 1
 timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1

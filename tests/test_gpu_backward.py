@@ -396,6 +396,19 @@ def test_local_pool_masked_fwd_bwd(ops, evidence, masked):
         assert float(np.abs(devi.cpu().double().numpy() - want_e).max()) <= 2e-5 * float(np.abs(want_e).max())
     else:
         assert devi is None
+    # the transposed form (the K-contiguous operand of the text-feature gradient's GEMM): same values, zero pad columns
+    dneg_t, devi_t = ops.local_pool_bwd(sim_t.to(DEV), dout.to(DEV), b, p, 0, c, evi_off, 50.0, 4.0, mask_tokens=mask, transposed=True)
+    rows = b * p
+    assert dneg_t.shape == (c, (rows + 31) // 32 * 32) and torch.equal(dneg_t[:, :rows].t().contiguous(), dneg) and not dneg_t[:, rows:].any()
+    if evidence:
+        assert torch.equal(devi_t[:, :rows].t().contiguous(), devi)
+    x = torch.from_numpy(synth.normal(8, "x", (37, 96))).to(DEV)
+    xt = ops.transpose_f32(x)
+    assert xt.shape == (96, 64) and torch.equal(xt[:, :37], x.t()) and not xt[:, 37:].any()
+    dy = torch.from_numpy(synth.normal(9, "dy", (37, 96))).to(DEV)
+    xr = x.double().cpu().requires_grad_(True)
+    (xr / xr.norm(dim=-1, keepdim=True)).backward(dy.double().cpu())
+    np.testing.assert_allclose(ops.l2norm_rows_bwd(x, dy).double().cpu().numpy(), xr.grad.numpy(), atol=1e-6, rtol=1e-5)
 
 
 def test_local_pool_many_positions(ops):
