@@ -965,3 +965,64 @@ def test_dense_clip_with_caption_features(ops, golden_dir):
     with torch.no_grad():
         plain = model(img.to(DEV), if_test=True)[0]
     assert float((plain - logits_).abs().max()) > 1e-3          # the mixing does change the global scores
+
+
+def _eval_batches_device():
+    g = torch.Generator().manual_seed(17)
+    out = []
+    for b, scales in ((5, (3, 4)), (1, (3, 4)), (4, (3, 4))):
+        lab = (torch.rand(b, 80, generator=g) < 0.1).long()
+        img = torch.from_numpy(synth.make_images(b, 32, seed=100 + b))
+        blocks = [torch.from_numpy(synth.make_images(b * w, 32, seed=200 + 10 * b + w)).reshape(b, w, 3, 32, 32) for w in scales]
+        out.append({"img": img, "label": lab, "img_blocks": blocks})
+    return out
+
+
+def _eval_trainer_device():
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_evaluator, build_trainer
+    cfg = get_cfg_default()
+    cfg.merge_from_list(["MODEL.BACKBONE.NAME", "tiny", "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", "(32, 32)", "TRAINER.Caption.PREC", "fp32",
+                         "TRAIN.MODEL", "DenseCLIP", "DATALOADER.TEST.BATCH_SIZE", "4"])
+    torch.manual_seed(3)
+    tr = build_trainer(cfg, evaluator=build_evaluator(cfg))
+    tr.test_loader = _eval_batches_device()
+    return tr
+
+
+def _eval_rank_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    from leclip_amd import parallel
+    parallel.init_from_env(backend="gloo")
+    tr = _eval_trainer_device()
+    value = tr.test()
+    q.put((rank, float(value), tr.evaluator.evaluate()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_test_sharded_two_ranks_on_device(ops):
+    """Caption_distill_double.test() sharded over two ranks (both on cuda:0, gloo transport) with the real DenseCLIP scorer: global +
+    local scores, sliding windows of two scales split by rank, a one-image batch - every metric equals the single-process run exactly
+    (window scores are batch-invariant bit for bit; max / min over windows combine exactly)."""
+    import socket
+    import torch.multiprocessing as mp
+    single = _eval_trainer_device()
+    want = float(single.test())
+    want_all = single.evaluator.evaluate()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_eval_rank_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, value, all_metrics in res:
+        assert value == want and all_metrics == want_all, (rank, value, want)
