@@ -468,13 +468,16 @@ def test_full_batch_properties(ops, dt):
             assert torch.equal(cc(img[256 - n:].contiguous(), if_test=True)[0], full[256 - n:])
 
 
-@pytest.mark.parametrize("dt,tol", [(torch.float16, 0.2), (torch.bfloat16, 0.6)])
-def test_map_against_oracle(ops, dt, tol):
+@pytest.mark.parametrize("dt,tol,claim", [(torch.float16, 0.2, "north-star clause"), (torch.bfloat16, 0.6, "regression bound only")])
+def test_map_against_oracle(ops, dt, tol, claim):
     """mAP over 80 labels of the HIP logits vs the fp32 CPU oracle's on the same 256 images, labels drawn from the
-    oracle logits.  North star: within +-0.2 - met by fp16, the reference's own GPU precision (model.py:470) and the
-    headline dtype of bench.py (measured 0.004 .. 0.03).  bf16 is bounded at what it achieves (measured 0.35 .. 0.43):
-    profiles/r02_lowprec_error_budget.py shows the gap is the 8-bit mantissa of the ACTIVATIONS themselves (any bf16
-    run of the reference would carry it; an fp32 residual stream only recovers a third of it), not an implementation loss."""
+    oracle logits.
+    fp16 - THE ACCURACY CLAIM: within +-0.2 (north star), the reference's own GPU precision (model.py:470) and the headline
+    dtype of bench.py (measured 0.004 .. 0.03).
+    bf16 - NO CLAIM: the companion dtype does not meet the +-0.2 clause on every sample (measured 0.17 .. 0.43) and is not
+    reported as meeting it (bench.py prints its own gate line for it); 0.6 here only guards against a
+    regression of the kernels.  profiles/r02_lowprec_error_budget.py shows the gap is the 8-bit mantissa of the ACTIVATIONS
+    themselves (any bf16 run of the reference would carry it; an fp32 residual stream recovers a third of it)."""
     from leclip_amd.config import get_cfg_default
     from leclip_amd.datasets import coco_object_categories
     from leclip_amd.evaluation import mAP
@@ -498,8 +501,8 @@ def test_map_against_oracle(ops, dt, tol):
         hip = cc(img.to(DEV), if_test=True)[0].float().cpu().numpy()
     labels = synth.make_labels_from_logits(ref, seed=7, pos_frac=0.1, noise=0.5)
     m_ref, m_hip = mAP(labels, ref), mAP(labels, hip)
-    print(f"mAP oracle {m_ref:.3f} hip[{dt}] {m_hip:.3f} max|dlogit| {np.abs(ref - hip).max():.3e}")
-    assert m_ref > 30 and abs(m_ref - m_hip) <= tol
+    print(f"mAP oracle {m_ref:.3f} hip[{dt}] {m_hip:.3f} max|dlogit| {np.abs(ref - hip).max():.3e}  ({claim}: <= {tol})")
+    assert m_ref > 30 and abs(m_ref - m_hip) <= tol, claim
 
 
 @pytest.mark.parametrize("dt", DTYPES)
