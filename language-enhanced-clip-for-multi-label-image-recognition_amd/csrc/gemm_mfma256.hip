@@ -102,6 +102,14 @@ __device__ __forceinline__ int xcd_remap256(int bid, int nwg) {
 
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
+// A wave-uniform pointer the compiler cannot prove uniform, moved to scalar registers (buffer descriptors must be scalar: a
+// descriptor it takes for divergent gets a waterfall loop around every access).
+__device__ __forceinline__ char* uniform_ptr(char* p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (char*)(((unsigned long long)hi << 32) | lo);
+}
+
 // SWAP: feed the MFMA with (W fragment, A fragment) instead of (A, W): the accumulator block (i, j) of lane l then holds
 // C[16i + (l & 15)][16j + 4(l >> 4) + r], r = 0..3 - one output row, four consecutive columns - instead of four rows of one
 // column (the fragments themselves are loaded identically: both operands are K-contiguous rows with the same lane map).
@@ -678,17 +686,32 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             if (!(DIAG(g.dbg) & 1)) {
                 constexpr int PITCH = 136, STRIP = 16 * PITCH;
                 char* st = smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES);
-                auto park16 = [&](int q) {
-                    int ln_ = lane_e;
-                    asm volatile("" : "+v"(ln_));
-                    const int m = ln_ & 15, gq = ln_ >> 4;
-                    float mean = 0.f, rstd = 1.f;
+                // Output stores go through a buffer descriptor rebuilt per tile on the scalar unit: base = this wave's first row and
+                // column, size = up to the last valid row - rows past M fall outside and the hardware drops their stores, so edge
+                // tiles run the same code with the same store count - and every store is (per-lane offset, scalar row offset):
+                // no 64-bit per-lane address arithmetic in the passes (it was 56 % of the vector instructions of this epilogue).
+                const int64_t row0 = em0 + wm * 128;
+                const int64_t left = g.M - row0;
+                const int rows_ok = left >= 128 ? 128 : (left > 0 ? (int)left : 0);
+                const int ldb = __builtin_amdgcn_readfirstlane((int)e.ldy * 2);   // (host: ldy < 2^22)
+                const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    uniform_ptr((char*)e.out + (row0 * e.ldy + en0 + wn * 64) * 2), 0,
+                    __builtin_amdgcn_readfirstlane(rows_ok ? (rows_ok - 1) * ldb + 128 : 0), 0x00020000);
+                // LayerNorm (mean, rstd) of strip q's rows: lane (m, g = q >> 1) holds them in lnpre[q & 1]
+                auto fetch_ln = [&](int q, float& mean, float& rstd) {
                     if constexpr (PF == 2) {
-                        const int src = ((ln_ & 15) | ((q >> 1) << 4)) << 2;   // lane (m, g = q >> 1) holds strip q's rows in lnpre[q & 1]
+                        int ln_ = lane_e;
+                        asm volatile("" : "+v"(ln_));
+                        const int src = ((ln_ & 15) | ((q >> 1) << 4)) << 2;
                         const float mean_l = lnpre[q & 1][0], rstd_l = lnpre[q & 1][1];
                         mean = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mean_l)));
                         rstd = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rstd_l)));
                     }
+                };
+                auto park16 = [&](int q, float mean, float rstd) {
+                    int ln_ = lane_e;
+                    asm volatile("" : "+v"(ln_));
+                    const int m = ln_ & 15, gq = ln_ >> 4;
                     char* sq = st + (q & 1) * STRIP + m * PITCH + gq * 8;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -704,33 +727,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                         *(v4t*)(sq + j * 32) = w;
                     }
                 };
-                auto passes16 = [&](auto check, auto nostore) {
-                    park16(0);
+                // Software-pipelined over the 8 strips: strip q's finished rows are read back (16 bytes per lane and row half)
+                // BEFORE strip q + 1 is converted and parked, and stored AFTER it - the LDS round trip of the reads and the
+                // bpermutes of strip q + 2's (mean, rstd) run under that strip's arithmetic, the stores sit between blocks of it.
+                auto passes16 = [&](auto nostore) {
+                    float mean1 = 0.f, rstd1 = 1.f, mean2 = 0.f, rstd2 = 1.f;
+                    fetch_ln(0, mean1, rstd1);
+                    park16(0, mean1, rstd1);
+                    fetch_ln(1, mean1, rstd1);
+                    int lane_q = lane_e;
+                    asm volatile("" : "+v"(lane_q));
+                    const int crow = lane_q >> 3, c16 = (lane_q & 7) * 16;
+                    const int voff = crow * ldb + c16;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
-                        if (q + 1 < 8) park16(q + 1);
-                        int lane_q = lane_e;
-                        asm volatile("" : "+v"(lane_q));
-                        const int crow = lane_q >> 3, c16 = (lane_q & 7) * 16;
-                        const int64_t row_base = em0 + wm * 128 + crow;
-                        T* optr = (T*)e.out + row_base * e.ldy + en0 + wn * 64 + (lane_q & 7) * 8;
+                        const char* sp = st + (q & 1) * STRIP + crow * PITCH + c16;
+                        const v4t r0 = *(const v4t*)sp, r1 = *(const v4t*)(sp + 8);
+                        const v4t r2 = *(const v4t*)(sp + 8 * PITCH), r3 = *(const v4t*)(sp + 8 * PITCH + 8);
+                        if (q + 2 < 8) fetch_ln(q + 2, mean2, rstd2);
+                        PIN();
+                        if (q + 1 < 8) park16(q + 1, mean1, rstd1);
+                        PIN();
+                        mean1 = mean2;
+                        rstd1 = rstd2;
+                        v8t o0, o1;
 #pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const char* sp = st + (q & 1) * STRIP + (u * 8 + crow) * PITCH + c16;
-                            const v4t lo = *(const v4t*)sp, hi = *(const v4t*)(sp + 8);
-                            const int roff = q * 16 + u * 8;
-                            if (decltype(check)::value && row_base + roff >= g.M) continue;
-                            v8t o8;
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) { o8[c] = lo[c]; o8[4 + c] = hi[c]; }
-                            if (decltype(nostore)::value && (float)o8[0] != 12345.678f) continue;
-                            *(v8t*)(optr + (int64_t)roff * e.ldy) = o8;
-                        }
+                        for (int c = 0; c < 4; ++c) { o0[c] = r0[c]; o0[4 + c] = r1[c]; o1[c] = r2[c]; o1[4 + c] = r3[c]; }
+                        if (decltype(nostore)::value && (float)o0[0] != 12345.678f) continue;
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o0), orsrc, voff, (q * 16) * ldb, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o1), orsrc, voff, (q * 16 + 8) * ldb, 0);
                     }
                 };
-                if (DIAG(g.dbg) & 2) passes16(BoolC<true>{}, BoolC<true>{});
-                else if (em0 + TM <= g.M) { passes16(BoolC<false>{}, BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
-                else passes16(BoolC<true>{}, BoolC<false>{});
+                if (DIAG(g.dbg) & 2) passes16(BoolC<true>{});
+                else { passes16(BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
             } else if (p.acc[0][0][0][0] == 12345.678f) {
                 ((float*)e.out)[0] = 1.f;
             }
@@ -882,7 +911,9 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
     const int tdt = sizeof(T) == 2 && __is_same(T, bf16_t) ? LECLIP_BF16 : LECLIP_F16;
     // specialised epilogues: output (and residual) in the operand dtype, no row remap, one of the six hot combinations
     const bool ln = e.ln_stats != nullptr;
-    const bool fast_ok = !force_generic && e.out_dt == tdt && !e.rowmap_P && (!e.res || e.res_dt == tdt) && !(e.res && ln);
+    // (leading dimensions below 2^22 elements: the specialised epilogues address a tile's rows with 32-bit buffer offsets)
+    const bool fast_ok = !force_generic && e.out_dt == tdt && !e.rowmap_P && (!e.res || e.res_dt == tdt) && !(e.res && ln) &&
+                         e.ldy < (1 << 22) && e.ldr < (1 << 22);
     if (fast_ok) {
         const bool gelu = e.act == LECLIP_ACT_QUICKGELU, stats = e.stats_out != nullptr;
         if (!e.res && !ln && !stats) return gelu ? launch256_pf<T, 0, 1>(a, grid, s) : launch256_pf<T, 0, 0>(a, grid, s);
