@@ -28,6 +28,47 @@ struct AttnArgs {
                         // (leclip_attention_prefix_fwd: the last block of the image tower needs the class token's row only)
 };
 
+constexpr int STREAM_TMAX = 640;
+template <int N> struct IntC { static constexpr int value = N; };
+typedef __attribute__((ext_vector_type(4))) int attn_i32x4;
+typedef __attribute__((ext_vector_type(2))) int attn_i32x2;
+
+__device__ __forceinline__ float lane32_max(float v) {   // max over the lane pair (l, l ^ 32), in both lanes
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float lane32_sum(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+
+// Output block of one 32-query block: lane (r = lane & 31, h = lane >> 5) holds O[q0 + r][32 i + 8 g + 4 h + e] in o[i][4 g + e].  The two
+// lanes of a query exchange halves (v_permlane32_swap, no LDS) so that each ends up with 8 consecutive columns: four 16-byte stores
+// per lane and block instead of eight 8-byte ones - the store tail of these kernels is bound by store ISSUE, not by bytes.
+template <typename T>
+__device__ __forceinline__ void attn_store_block(const f32x16 (&o)[2], float inv, T* op, int fh, bool on) {
+    typedef typename VecOf<T>::v4 v4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v4 wa, wb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wa[e] = (T)(o[i][8 * k + e] * inv); wb[e] = (T)(o[i][8 * k + 4 + e] * inv); }
+            const u32x2 a2 = __builtin_bit_cast(u32x2, wa), b2 = __builtin_bit_cast(u32x2, wb);
+            // swap(X = a, Y = b): X[32..63] <-> Y[0..31].  h = 0: (own a, partner's a) = columns +0..7; h = 1: (partner's b, own b) = +8..15
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
+            attn_i32x4 w;
+            w[0] = (int)s0[0]; w[1] = (int)s1[0]; w[2] = (int)s0[1]; w[3] = (int)s1[1];
+            if (on) *(attn_i32x4*)(op + 32 * i + 16 * k + 8 * fh) = w;
+        }
+}
+
 // One 32-query block of one (batch, head): S^T = K.Q^T, masked softmax over keys, O^T = V^T.P^T, store.
 // sK / sV: the head's K and V images in LDS (swizzled as described above); `base` points at q[b, 0, head, 0].
 // Q fragments of a 32-query block (MFMA B operand): lane (r = lane&31, h = lane>>5) holds Q[q0 + r][16s + 8h + j].
@@ -65,20 +106,37 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
         if constexpr (STORE_ALL) {
             // pipelined kernel: K fragments one key tile (4 reads) ahead of their MFMAs - the wave's S -> softmax -> O chain,
             // not HBM, is what bounds that kernel, so its LDS round trips are taken off the chain
-            v8 kfr[2][4];
+            // Written as plain loads (round 2: "one key tile ahead") hipcc serialised this phase: every MFMA behind an
+            // s_waitcnt lgkmcnt(0) for its own, just issued ds_read_b128 - one exposed LDS round trip per MFMA, 28 per head, the
+            // matrix pipe idle three quarters of the phase.  The reads are inline asm (invisible to the scheduler, which cannot
+            // then fold the ring back into one register set), a ring of KR fragments, KR - 1 reads ahead of the MFMA that
+            // consumes them; the counted wait carries the fragment as an in/out operand, so the MFMA cannot move above it.
+            typedef __attribute__((ext_vector_type(4))) int i32x4;
+            constexpr int KR = 4, NST = 4 * NKT;
+            unsigned ka[4];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) kfr[0][s] = *(const v8*)(kbase[s]);
+            for (int s = 0; s < 4; ++s) ka[s] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)kbase[s];
+            i32x4 kr[KR];
+#define K_ISSUE(step) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(step) % KR]) : "v"(ka[(step) & 3]), "n"(((step) >> 2) * 4096))
 #pragma unroll
-            for (int kt = 0; kt < NKT; ++kt) {
-                if (kt + 1 < NKT) {
+            for (int st = 0; st < KR - 1; ++st) K_ISSUE(st);
 #pragma unroll
-                    for (int s = 0; s < 4; ++s) kfr[(kt + 1) & 1][s] = *(const v8*)(kbase[s] + (kt + 1) * 4096);
+            for (int st = 0; st < NST; ++st) {
+                const int kt = st >> 2, s = st & 3;
+                if (st + KR - 1 < NST) K_ISSUE(st + KR - 1);
+                // DS operations return in order: all but the reads of the younger steps have arrived
+                if (st + KR - 1 < NST) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kr[st % KR]) : "n"(KR - 1));
+                else if (st + 2 < NST) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kr[st % KR]));
+                else if (st + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kr[st % KR]));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[st % KR]));
+                if (s == 0) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
                 }
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
-#pragma unroll
-                for (int s = 0; s < 4; ++s) sc[kt] = mfma_32x32x16(kfr[kt & 1][s], qf[s], sc[kt]);
+                sc[kt] = mfma_32x32x16(__builtin_bit_cast(v8, kr[st % KR]), qf[s], sc[kt]);
+                __builtin_amdgcn_sched_barrier(0);
             }
+#undef K_ISSUE
         } else {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
@@ -111,7 +169,7 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = lane32_max(mx);   // the query's other lane (v_permlane32_swap: no LDS round trip)
         float sum = 0.f;
         const float mb = mx * a.scale_log2e;
 #pragma unroll
@@ -123,7 +181,7 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                 sc[kt][r] = p;
                 sum += p;
             }
-        sum += __shfl_xor(sum, 32);
+        sum = lane32_sum(sum);
         const float inv = 1.0f / sum;
 
         // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
@@ -198,26 +256,14 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
             }
 #undef TR_ISSUE
         }
-        // ---- store: lane owns query qi; registers 4g..4g+3 are 4 consecutive d
-        if (STORE_ALL || qi < a.T) {
-            T* op = obase + (int64_t)(STORE_ALL ? qrow : qi) * a.ld_out;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    v4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
-                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
-                }
-        }
+        // ---- store: lane owns query qi
+        attn_store_block<T>(o, inv, obase + (int64_t)(STORE_ALL ? qrow : qi) * a.ld_out, fh, STORE_ALL || qi < a.T);
     }
 }
 
 template <typename T, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
     typedef typename VecOf<T>::v8 v8;
-    typedef typename VecOf<T>::v4 v4;
     constexpr int TP = NKT * 32;
     __shared__ __attribute__((aligned(16))) char sK[TP * 128];
     __shared__ __attribute__((aligned(16))) char sV[TP * 128];
@@ -267,8 +313,8 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
 // 512 threads = 8 waves, one persistent workgroup per CU walking (batch, head) pairs.  K/V of head i+1 stream into the
 // second LDS buffer by LDS-DMA (global_load_lds_dwordx4; the swizzles are applied to the per-lane SOURCE address, rows past
 // T re-read row T-1: masked keys / zero probabilities make them inert) and its Q fragments into registers while head i
-// is computed; wave w owns query block w.  The wait is counted: every wave ends a head with exactly 8 output stores,
-// so "all but the newest 8" retires its share of the next head's K/V and Q without draining those stores.  One barrier
+// is computed; wave w owns query block w.  The wait is counted: every wave ends a head with exactly 4 output stores,
+// so "all but the newest 4" retires its share of the next head's K/V and Q without draining those stores.  One barrier
 // per head.
 template <typename T, int NKT>
 __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int total_heads) {
@@ -341,15 +387,15 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
             v8 q[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) q[s] = *(const v8*)(qrd + (((2 * s + qh) ^ qsw) << 4));
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // Q fragments are in registers: the Q image may be refilled
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), as the compiler's own instruction (its scoreboard then knows the Q fragments are in: no second wait in front of the first MFMA): the Q image may be refilled
             issue(nb, cur ^ 1);
             issue_q(nb);
             const int b = hd / a.heads, h = hd - b * a.heads;
             T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
             attn_qblock<T, NKT, true>(a, smem + cur * 2 * BUF, smem + cur * 2 * BUF + BUF, q, obase, wave, lane);
-            // Everything older than this head's 8 output stores has completed: the next head's K/V share and Q image
+            // Everything older than this head's 4 output stores has completed: the next head's K/V share and Q image
             // (issued a whole head ago) are in, without draining the stores just issued.
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         } else {
             // a wave without a query block (wave 7 when T <= 224) only moves its share of K/V
             issue(nb, cur ^ 1);
@@ -363,17 +409,157 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 }
 
 // ---------------------------------------------------------------- streaming kernel for long sequences (ViT-L/14@336: T = 577)
-// One 512-thread workgroup per (batch, head); the head's whole K and V (T <= 640: 2 x 80 KiB) sit in LDS, each wave
-// owns 32-query blocks and walks the keys in chunks of 4 tiles (128 keys) with the online-softmax recurrence: running
-// row maximum m and normaliser l live in the two lanes that hold a query, O^T accumulators are rescaled by
-// exp2(scale*(m_old - m_new)) when the maximum moves.  Same MFMA formulation as attn_qblock (S^T = K.Q^T, P fed back
-// as the B operand, V^T by ds_read_b64_tr_b16).
-constexpr int STREAM_TMAX = 640;
+// One 512-thread workgroup per (batch, head); the head's whole K and V (T <= 640: 2 x 80 KiB) sit in LDS, each wave owns 32-query
+// blocks and walks the keys in chunks of 4 tiles (128 keys) with the online-softmax recurrence: the running row maximum m lives in
+// the two lanes that hold a query, O^T accumulators are rescaled by exp2(scale*(m_old - m_new)) when the maximum moves.  Same MFMA
+// formulation as attn_qblock (S^T = K.Q^T, P fed back as the B operand, V^T by ds_read_b64_tr_b16).
+// Round 3 wrote the per-chunk chain out by hand: round 2's plain source compiled to ~600 vector
+// instructions per chunk and wave - 64 zero-initialising moves (tiles that might be skipped), 64 moves merging the masked and the
+// unmasked path, two ds_bpermute round trips for the row maximum and sum - behind LDS reads that each MFMA waited for.  Here:
+//   * chunks are templates on (tiles, mask mode): the full chunks run branch-free, only the last tile of the last chunk is masked;
+//   * K fragments and V^T fragments come from inline-asm reads in rings (3 / 2 steps ahead of their MFMAs), the first V^T
+//     fragments are requested before the softmax arithmetic; counted lgkmcnt waits tied to the registers they release;
+//   * the row maximum crosses the two lanes of a query with v_permlane32_swap (no LDS); the row SUM stays a per-lane partial
+//     for the whole query block (both lanes scale it by the same factors) and is combined once, at the end;
+//   * scale / subtract, the sum and the rescaling of O are packed fp32 operations (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
+// One chunk of NT key tiles (32 keys each) against the wave's 32-query block.  ka[s] / va0 / va1: this lane's LDS byte addresses
+// of the chunk's first K fragment row (k-step s) and V^T blocks; lim = (last valid key) - (chunk's first key) - 4 * (lane >> 5).
+// MASK: 0 none, 1 the last tile only, 2 every tile (causal).
+template <typename T, int NT, int MASK>
+__device__ __forceinline__ void stream_chunk(const unsigned (&ka)[4], unsigned va0, unsigned va1, const typename VecOf<T>::v8 (&qf)[4],
+                                             f32x16 (&o)[2], float& m_run, float& l_part, float c, int lim) {
+    typedef typename VecOf<T>::v8 v8;
+    constexpr int KR = 8, KA = KR - 1, VR = 4, VA = VR - 1, NST = 4 * NT, NPV = 2 * NT;   // (ring depths 4 / 3 and 6 / 3 measure the same)
+    f32x16 sc[NT];
+    attn_i32x4 kr[KR];
+    attn_i32x2 vr[VR][4];   // [PV step % VR][d block * 2 + key half]
+#define SK_ISSUE(step) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(kr[(step) % KR]) : "v"(ka[(step) & 3]), "n"(((step) >> 2) * 4096))
+#define SV_ISSUE(step)                                                                                                          \
+    _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                            \
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[(step) % VR][i_ * 2 + u_]) : "v"(i_ ? va1 : va0),           \
+                     "n"((((step) >> 1) * 32 + 16 * ((step) & 1) + 8 * u_) * 128))
+    // s_waitcnt lgkmcnt(n) with the registers it releases as in/out operands: nothing that reads them can be scheduled above it
+#define SK_WAIT(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n))
+    // ---- S^T = K . Q^T.  DS operations return in order: a read has arrived once at most the reads issued after it are outstanding.
+#pragma unroll
+    for (int st = 0; st < KA && st < NST; ++st) SK_ISSUE(st);
+#pragma unroll
+    for (int st = 0; st < NST; ++st) {
+        const int kt = st >> 2, s = st & 3;
+        if (st + KA < NST) SK_ISSUE(st + KA);
+        switch (st + KA < NST ? KA : NST - 1 - st) {   // (compile-time after unrolling)
+            case 0: SK_WAIT(0, kr[st % KR]); break;
+            case 1: SK_WAIT(1, kr[st % KR]); break;
+            case 2: SK_WAIT(2, kr[st % KR]); break;
+            case 3: SK_WAIT(3, kr[st % KR]); break;
+            case 4: SK_WAIT(4, kr[st % KR]); break;
+            case 5: SK_WAIT(5, kr[st % KR]); break;
+            case 6: SK_WAIT(6, kr[st % KR]); break;
+            default: SK_WAIT(7, kr[st % KR]); break;
+        }
+        static_assert(KA <= 7, "wait table");
+        const v8 kf = __builtin_bit_cast(v8, kr[st % KR]);
+        if (s == 0) {
+            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            sc[kt] = mfma_32x32x16(kf, qf[s], z);
+        } else {
+            sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // the first V^T fragments travel under the softmax arithmetic
+#pragma unroll
+    for (int st = 0; st < VA && st < NPV; ++st) SV_ISSUE(st);
+    // ---- mask, running maximum
+    float mx = m_run;
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt) {
+        if (MASK == 2 || (MASK == 1 && kt == NT - 1)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] = lim >= kt * 32 + (r & 3) + 8 * (r >> 2) ? sc[kt][r] : -3.0e38f;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc[kt][r]), sc[kt][r + 1]);   // (v_max3_f32)
+    }
+    mx = lane32_max(mx);
+    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * c);   // first chunk: exp2(-huge) = 0
+    m_run = mx;
+    const f32x2 c2 = {c, c}, nmb2 = {-mx * c, -mx * c};
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const f32x2 x = {sc[kt][r], sc[kt][r + 1]};
+            const f32x2 e = __builtin_elementwise_fma(x, c2, nmb2);
+            f32x2 pv;
+            pv[0] = __builtin_amdgcn_exp2f(e[0]);   // arguments are <= 0; masked keys: exp2(-huge) = exactly 0
+            pv[1] = __builtin_amdgcn_exp2f(e[1]);
+            sc[kt][r] = pv[0];
+            sc[kt][r + 1] = pv[1];
+            sum2 += pv;
+        }
+    l_part = fmaf(l_part, alpha, sum2[0] + sum2[1]);
+    const f32x2 a2 = {alpha, alpha};
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            f32x2 t = {o[i][r], o[i][r + 1]};
+            t *= a2;
+            o[i][r] = t[0];
+            o[i][r + 1] = t[1];
+        }
+    // ---- O^T += V^T . P^T
+#pragma unroll
+    for (int st = 0; st < NPV; ++st) {
+        const int kt = st >> 1, s2 = st & 1, slot = st % VR;
+        if (st + VA < NPV) SV_ISSUE(st + VA);
+        v8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
+#define SV_WAIT(n) asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(vr[slot][0]), "+v"(vr[slot][1]), "+v"(vr[slot][2]), "+v"(vr[slot][3]) : "n"(n))
+        switch (st + VA < NPV ? VA : NPV - 1 - st) {
+            case 0: SV_WAIT(0); break;
+            case 1: SV_WAIT(4); break;
+            case 2: SV_WAIT(8); break;
+            default: SV_WAIT(12); break;
+        }
+        static_assert(VA <= 3, "wait table");
+#undef SV_WAIT
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            attn_i32x4 w;
+            w[0] = vr[slot][i * 2][0]; w[1] = vr[slot][i * 2][1]; w[2] = vr[slot][i * 2 + 1][0]; w[3] = vr[slot][i * 2 + 1][1];
+            o[i] = mfma_32x32x16(__builtin_bit_cast(v8, w), pf, o[i]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef SK_ISSUE
+#undef SV_ISSUE
+#undef SK_WAIT
+}
 
-template <typename T>
+#ifdef LECLIP_ATTN_STAMPS   // diagnostic variant builds only: shader-clock stamps of waves 0 and 4 of the first 2048 workgroups
+__device__ unsigned long long g_attn_stamps[2048 * 2 * 16];
+#define ASTAMP(k)                                                                                                   \
+    do {                                                                                                            \
+        if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 2048)                                                      \
+            g_attn_stamps[(blockIdx.x * 2 + (wave >> 2)) * 16 + (k)] = __builtin_amdgcn_s_memtime();                \
+    } while (0)
+#define ASTAMP_RT(k)                                                                                                \
+    do {                                                                                                            \
+        if ((wave & 3) == 0 && lane == 0 && blockIdx.x < 2048)                                                      \
+            g_attn_stamps[(blockIdx.x * 2 + (wave >> 2)) * 16 + (k)] = __builtin_amdgcn_s_memrealtime();            \
+    } while (0)
+#else
+#define ASTAMP(k) do { } while (0)
+#define ASTAMP_RT(k) do { } while (0)
+#endif
+
+template <typename T, bool CAUSAL>
 __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP) {
     typedef typename VecOf<T>::v8 v8;
-    typedef typename VecOf<T>::v4 v4;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // K [TP][128 B] | V [TP][128 B]
     char* sK = smem;
     char* sV = smem + TP * 128;
@@ -382,144 +568,118 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
     const int d_model = a.heads * 64;
     const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
-    // Stage K and V by LDS-DMA, every piece (8 rows x 128 B) of the head in flight at once: TP / 4 pieces, TP / 32 per wave (20 at
-    // T = 577).  Round 2 staged through registers, one 64-row pass at a time - ten dependent HBM round trips per head in front of the
-    // first MFMA, a third of the kernel at T = 577.  The swizzles are applied to the per-lane SOURCE address; rows past T re-read
-    // row T - 1 (their keys are masked, their probabilities exactly 0), as in attn_heads_kernel.
-    for (int pc = wave; pc < TP / 4; pc += 8) {
-        const int isv = pc >= TP / 8 ? 1 : 0;
-        const int piece = pc - isv * (TP / 8);
-        const int row = piece * 8 + (lane >> 3);
-        const int p = lane & 7;
-        const int c = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
-        const int grow = row < a.T ? row : a.T - 1;
-        const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + c * 8;
-        __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
+    ASTAMP(0);
+    ASTAMP_RT(14);
+    // The wave's first query block is requested first, then K and V by LDS-DMA, every piece (8 rows x 128 B) of the head in flight
+    // at once.  (Starting chunk c of the first query block as soon as the pieces of chunks 0 .. c have landed - pieces issued in
+    // chunk order, a counted vmcnt and a barrier per chunk - was built and measured 5 % SLOWER: a CU takes the 148 KB of a head in
+    // at 13 bytes per cycle whatever the order, the first chunk's pieces land almost as late as the last one's, and the loads then
+    // run beside the first block's arithmetic instead of in front of it; profiles/r03_attention_stream.txt.)
+    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5;
+    const int nch = TP >> 7;
+    // (inline asm, released by the wait below: the compiler then has no pending load on these registers at the head of the query-block
+    // loop and puts no s_waitcnt vmcnt(0) in front of every block's first MFMA - where it would wait for the NEXT block's Q, just requested)
+    attn_i32x4 q0[4];
+    {
+        const int qi = wave * 32 + (lane & 31);
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q0[s]) : "v"(qp), "n"(s * 32));
     }
-    // the wave's first query block travels beside the K/V pieces; every later block's Q is requested one block ahead (the loads sat
-    // in front of each block's first MFMA in round 2: one exposed HBM round trip per 32 queries)
-    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5, nchunk = TP >> 7;
+    for (int ch = 0; ch < nch; ++ch) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int isv = u >> 1;
+            const int piece = ch * 16 + wave + 8 * (u & 1);
+            const int row = piece * 8 + (lane >> 3);
+            const int p = lane & 7;
+            const int cc = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+            const int grow = row < a.T ? row : a.T - 1;
+            const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + cc * 8;
+            __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]) : : "memory");
+    __builtin_amdgcn_s_barrier();
     v8 qf[4];
-    if (wave < nqb) attn_load_q<T>(a, base, wave, lane, qf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, q0[s]);
+    ASTAMP(1);
+    ASTAMP(2);
 
     const int fr = lane & 31, fh = lane >> 5;
     const int li = lane & 15, dgrp = (lane >> 4) & 1;
-    const char* kbase[4];
-    const char* vbase[2];
+    unsigned ka0[4];
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kbase[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+    for (int s = 0; s < 4; ++s)
+        ka0[s] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4));
+    unsigned vb[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-        vbase[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
-
+        vb[i] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) +
+                                                                                     32 * dgrp + 8 * (li & 3));
+    const float c = a.scale_log2e;
+    const int nfull = CAUSAL ? 0 : a.T >> 7;                  // chunks whose 128 keys are all valid (image tower: no mask at all)
+    const int tail_keys = a.T - (nfull << 7);                 // 0 .. 127 keys in the last, partial chunk
     T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
     for (int qb = wave; qb < nqb; qb += 8) {
+        const bool has_next = qb + 8 < nqb;
         v8 qn[4];
-        if (qb + 8 < nqb) attn_load_q<T>(a, base, qb + 8, lane, qn);
+        if (has_next) attn_load_q<T>(a, base, qb + 8, lane, qn);
         const int qi = qb * 32 + fr;
         const int qrow = qi < a.T ? qi : a.T - 1;
-        const int klimit = a.causal ? qrow : a.T - 1;
-        float m_run = -3.0e38f, l_run = 0.f;
+        float m_run = -3.0e38f, l_part = 0.f;
         f32x16 o[2];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-        for (int ch = 0; ch < nchunk; ++ch) {
-            const int key0 = ch * 128;
-            if (a.causal && key0 > qb * 32 + 31) break;   // wave-uniform: every key of this chunk is masked for the block
-            f32x16 sc[4];
+        auto chunk_at = [&](int key0, auto nt, auto mask, int klimit) {
+            unsigned ka[4];
 #pragma unroll
-            for (int kt = 0; kt < 4; ++kt) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
-                if (key0 + kt * 32 > a.T - 1) continue;      // a key tile wholly past T (wave-uniform): no MFMA, masked below
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    const v8 kf = *(const v8*)(kbase[s] + (key0 + kt * 32) * 128);
-                    sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
-                }
+            for (int s = 0; s < 4; ++s) ka[s] = ka0[s] + key0 * 128;
+            stream_chunk<T, decltype(nt)::value, decltype(mask)::value>(ka, vb[0] + key0 * 128, vb[1] + key0 * 128, qf, o, m_run, l_part, c,
+                                                                          klimit - key0 - 4 * fh);
+        };
+        auto tail_at = [&](int key0, int keys, auto mask, int klimit) {   // a chunk with 1 .. 128 keys that may hold valid ones
+            const int nt = (keys + 31) >> 5;                             // wave-uniform
+            if (nt == 1) chunk_at(key0, IntC<1>{}, mask, klimit);
+            else if (nt == 2) chunk_at(key0, IntC<2>{}, mask, klimit);
+            else if (nt == 3) chunk_at(key0, IntC<3>{}, mask, klimit);
+            else chunk_at(key0, IntC<4>{}, mask, klimit);
+        };
+        if constexpr (!CAUSAL) {
+            for (int ch = 0; ch < nfull; ++ch) chunk_at(ch << 7, IntC<4>{}, IntC<0>{}, a.T - 1);
+            if (tail_keys > 0) tail_at(nfull << 7, tail_keys, IntC<1>{}, a.T - 1);
+        } else {
+            // causal: keys 0 .. qrow; the block's last query is min(qb * 32 + 31, T - 1) (wave-uniform bound on the chunks visited)
+            const int last_q = qb * 32 + 31 < a.T - 1 ? qb * 32 + 31 : a.T - 1;
+            for (int key0 = 0; key0 <= last_q; key0 += 128) {
+                const int keys = last_q + 1 - key0 < 128 ? last_q + 1 - key0 : 128;
+                tail_at(key0, keys, IntC<2>{}, qrow);
             }
-            float mx = m_run;
-            // only a chunk that reaches past the last valid key needs the per-element mask (wave-uniform test): for the image tower
-            // that is the final chunk alone - two vector instructions per score saved on the others
-            if (a.causal || key0 + 127 > a.T - 1) {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                        const float v = key <= klimit ? sc[kt][r] : -3.0e38f;
-                        sc[kt][r] = v;
-                        mx = fmaxf(mx, v);
-                    }
-            } else {
-#pragma unroll
-                for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 32));
-            const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * a.scale_log2e);   // first chunk: exp2(-huge) = 0
-            m_run = mx;
-            const float mb = mx * a.scale_log2e;
-            float sum = 0.f;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], a.scale_log2e, -mb));
-                    sc[kt][r] = p;
-                    sum += p;
-                }
-            sum += __shfl_xor(sum, 32);
-            l_run = l_run * alpha + sum;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt)
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    if (key0 + kt * 32 > a.T - 1) continue;  // every probability of the tile is exactly 0
-                    v8 pf;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        v8 vf;
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const v4 t4 = lds_read_tr16((const T*)(vbase[i] + (key0 + kt * 32 + 16 * s2 + 8 * u) * 128));
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) vf[4 * u + e] = t4[e];
-                        }
-                        o[i] = mfma_32x32x16(vf, pf, o[i]);
-                    }
-                }
         }
-        const float inv = 1.0f / l_run;
-        if (qi < a.T) {
-            T* op = obase + (int64_t)qi * a.ld_out;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int g4 = 0; g4 < 4; ++g4) {
-                    v4 w;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) w[e] = (T)(o[i][4 * g4 + e] * inv);
-                    *(v4*)(op + 32 * i + 8 * g4 + 4 * fh) = w;
-                }
-        }
-        if (qb + 8 < nqb) {
+        ASTAMP(3 + 2 * (qb >> 3));
+        // the next block's Q (requested a whole block ago) moves in BEFORE this block's stores: the compiler's wait for it then
+        // drains nothing else (behind the stores - their number is exec-dependent to the compiler - it is a vmcnt(0) that waits for them too)
+        if (has_next) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[s] = qn[s];
         }
+        const float inv = 1.0f / lane32_sum(l_part);
+        attn_store_block<T>(o, inv, obase + (int64_t)qi * a.ld_out, fh, qi < a.T);
+        ASTAMP(4 + 2 * (qb >> 3));
     }
+    ASTAMP(12);
+    ASTAMP_RT(15);
 }
+
+#ifdef LECLIP_ATTN_STAMPS
+extern "C" int leclip_attn_stamps_read(unsigned long long* host, size_t n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), n * sizeof(unsigned long long));
+}
+#endif
 
 // ---------------------------------------------------------------- fp32 validation kernel
 // One workgroup per (batch, head), K and V in LDS as fp32 (rows padded to 65 floats), one query row per wave at
@@ -614,8 +774,14 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     else if (a.T <= STREAM_TMAX) {
         const int TP = (a.T + 127) & ~127;
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
-        leclip_set_max_lds(attn_stream_kernel<T>, STREAM_TMAX * 256, attr_set);
-        hipLaunchKernelGGL((attn_stream_kernel<T>), dim3(grid), dim3(512), TP * 256, s, a, TP);
+        static bool attr_set_c[LECLIP_MAX_DEVICES] = {};
+        if (a.causal) {
+            leclip_set_max_lds(attn_stream_kernel<T, true>, STREAM_TMAX * 256, attr_set_c);
+            hipLaunchKernelGGL((attn_stream_kernel<T, true>), dim3(grid), dim3(512), TP * 256, s, a, TP);
+        } else {
+            leclip_set_max_lds(attn_stream_kernel<T, false>, STREAM_TMAX * 256, attr_set);
+            hipLaunchKernelGGL((attn_stream_kernel<T, false>), dim3(grid), dim3(512), TP * 256, s, a, TP);
+        }
         return leclip_check_launch("attn_stream_kernel");
     } else {
         leclip_set_error("attention: T=%d > %d is not supported in 16-bit modes", a.T, STREAM_TMAX);

@@ -10,6 +10,7 @@
 #include <cstring>
 #include <random>
 #include <vector>
+#include <algorithm>
 #include "../../../include/leclip_hip.h"
 
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
@@ -178,6 +179,68 @@ static void bench() {
 }
 
 
+// Attention alone: the many-heads kernels at the grids the model launches them with (kernel_check's default cases stay below
+// the 1024-head threshold of the pipelined ViT-B kernel), checked against the double-precision reference, then timed.
+static int attn() {
+    const bool bench_only = getenv("LECLIP_ATTN_BENCH_ONLY") != nullptr;   // ablation builds compute garbage: timings only
+    const char* only = getenv("LECLIP_ATTN_SHAPES");                      // "B" / "L": ViT-B or ViT-L shapes only
+    if (!bench_only) for (int dt : {LECLIP_F16, LECLIP_BF16}) {
+        check_attn(86, 197, 12, dt, 0);    // 1032 heads: attn_heads_kernel
+        check_attn(90, 200, 12, dt, 0);
+        check_attn(2, 577, 16, dt, 0);     // attn_stream_kernel
+        check_attn(1, 640, 3, dt, 0);
+        check_attn(1, 300, 2, dt, 1);
+    }
+    printf(g_fail ? "FAILED %d checks\n" : "ALL OK\n", g_fail);
+    if (g_fail) return 1;
+    struct S { int B, T, heads; const char* name; } shapes[] = {{256, 197, 12, "ViT-B/16 B=256"}, {128, 197, 12, "ViT-B/16 B=128"}, {128, 577, 16, "ViT-L/14@336 B=128"}, {64, 577, 16, "ViT-L/14@336 B=64"}};
+    for (int round = 0; round < 2; ++round)
+        for (auto& s : shapes) for (int dt : {LECLIP_F16, LECLIP_BF16}) {
+            if (only && ((only[0] == 'L') != (s.T == 577))) continue;
+            const int d = s.heads * 64;
+            auto Q = randn((size_t)s.B * s.T * 3 * d, 0.8f);
+            auto Qp = pack(Q, dt);
+            Buf dQ(Qp.size()), dO((size_t)s.B * s.T * d * 2);
+            dQ.up(Qp.data());
+            double ms = time_ms(50, [&] { leclip_attention_fwd(dQ.d, dO.d, s.B, s.T, s.heads, 64, 3 * d, d, LECLIP_MASK_NONE, 0.125f, (leclip_dtype)dt, nullptr); });
+            printf("bench attn %-20s %s: %.1f us  %.1f TFLOP/s  %.2f TB/s\n", s.name, dtn(dt), ms * 1e3, 4.0 * s.T * s.T * 64 * s.B * s.heads / ms * 1e-9,
+                   (double)s.B * s.T * d * 2 * 4 / ms * 1e-9);
+        }
+    return 0;
+}
+
+// Diagnostic (variant builds with -DLECLIP_ATTN_STAMPS): where a workgroup of the streaming attention kernel spends its time.
+extern "C" int leclip_attn_stamps_read(unsigned long long* host, size_t n) __attribute__((weak));
+static int attnstamps() {
+    if (!leclip_attn_stamps_read) { printf("library built without attention stamps\n"); return 1; }
+    const int B = 128, T = 577, heads = 16, d = heads * 64, dt = LECLIP_F16;
+    auto Q = randn((size_t)B * T * 3 * d, 0.8f);
+    auto Qp = pack(Q, dt);
+    Buf dQ(Qp.size()), dO((size_t)B * T * d * 2);
+    dQ.up(Qp.data());
+    for (int i = 0; i < 20; ++i) leclip_attention_fwd(dQ.d, dO.d, B, T, heads, 64, 3 * d, d, LECLIP_MASK_NONE, 0.125f, (leclip_dtype)dt, nullptr);
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned long long> st(2048 * 2 * 16);
+    leclip_attn_stamps_read(st.data(), st.size());
+    const char* names[] = {"staging issue+wait", "barrier", "block 1 chunks", "block 1 stores", "block 2 chunks", "block 2 stores", "block 3 chunks", "block 3 stores"};
+    for (int w = 0; w < 2; ++w) {
+        std::vector<double> seg[8], total, clk;
+        for (int g = 0; g < 2048; ++g) {
+            const unsigned long long* e = &st[(g * 2 + w) * 16];
+            const int nb = w == 0 ? 3 : 2;
+            unsigned long long prev = e[0];
+            const unsigned long long pts[8] = {e[1], e[2], e[3], e[4], e[5], e[6], e[7], e[8]};
+            for (int k = 0; k < 2 + 2 * nb; ++k) { seg[k].push_back((double)(pts[k] - prev)); prev = pts[k]; }
+            total.push_back((double)(e[12] - e[0]));
+            if (e[15] > e[14]) clk.push_back((double)(e[12] - e[0]) / (double)(e[15] - e[14]) * 0.1);   // GHz: shader cycles per 10 ns tick
+        }
+        auto med = [](std::vector<double>& v) { if (v.empty()) return 0.0; std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+        printf("wave %d: workgroup lifetime median %.0f cycles, in-kernel clock median %.2f GHz\n", w * 4, med(total), med(clk));
+        for (int k = 0; k < 8; ++k) if (!seg[k].empty()) printf("    %-20s median %8.0f cycles\n", names[k], med(seg[k]));
+    }
+    return 0;
+}
+
 // Diagnostic: in-kernel timeline of the 256x256 GEMM (needs the library built with -DLECLIP_GEMM_STAMPS: make stamps).
 extern "C" void leclip_gemm256_set_stamps(unsigned long long* device_buf) __attribute__((weak));
 static void stamps() {
@@ -278,6 +341,8 @@ int main(int argc, char** argv) {
     printf("leclip ABI %d\n", leclip_abi_version());
     if (argc > 1 && !strcmp(argv[1], "bench")) { bench(); return 0; }
     if (argc > 1 && !strcmp(argv[1], "stamps")) { stamps(); return 0; }
+    if (argc > 1 && !strcmp(argv[1], "attn")) { return attn(); }
+    if (argc > 1 && !strcmp(argv[1], "attnstamps")) { return attnstamps(); }
     check_gemm_identity();
     for (int dt : {LECLIP_BF16, LECLIP_F16}) {
         check_gemm(200, 128, 64, dt, LECLIP_F32, LECLIP_F32, 0, false, false);
