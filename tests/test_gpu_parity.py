@@ -235,6 +235,26 @@ def test_attention(ops, dt, cfg):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(1, 577, 3, False), (2, 640, 1, False), (1, 257, 2, False), (1, 225, 1, False), (1, 512, 1, False), (1, 300, 2, True),
+                                 (1, 385, 1, True), (1, 640, 1, True)])
+def test_attention_long(ops, dt, cfg):
+    """225 .. 640 tokens run the streaming kernel (attn_stream_kernel: 128-key chunks, online softmax): whole chunks only (512), a last
+    chunk of one key (257, 385), of one tile plus one key (225 -> 97 keys in chunk 1), of 65 keys (577: ViT-L/14@336), the full 640, and
+    the causal form, whose chunks are masked per element and end at the query block's diagonal."""
+    b, t, h, causal = cfg
+    d = 64 * h
+    qkv = _rand((b * t, 3 * d), 13).to(dt)
+    q, k, v = [z.reshape(b, t, h, 64).transpose(1, 2).double() for z in qkv.float().split(d, dim=-1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.triu(torch.full((t, t), float("-inf"), dtype=torch.float64), 1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b * t, d)
+    y = ops.attention(qkv.to(DEV), b, t, h, causal)
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-5, 4e-3, 2.5e-2), rtol=0)
+    assert torch.equal(y, ops.attention(qkv.to(DEV), b, t, h, causal))     # deterministic
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(86, 197, 12), (43, 224, 24), (22, 193, 48), (300, 197, 12)])
 def test_attention_many_heads(ops, dt, cfg):
     """>= 1024 (batch, head) pairs with 193..224 tokens run the persistent pipelined kernel (attn_heads_kernel): head counts
