@@ -424,12 +424,34 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 //   * scale / subtract, the sum and the rescaling of O are packed fp32 operations (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
 // One chunk of NT key tiles (32 keys each) against the wave's 32-query block.  ka[s] / va0 / va1: this lane's LDS byte addresses
 // of the chunk's first K fragment row (k-step s) and V^T blocks; lim = (last valid key) - (chunk's first key) - 4 * (lane >> 5).
-// MASK: 0 none, 1 the last tile only, 2 every tile (causal).
-template <typename T, int NT, int MASK>
-__device__ __forceinline__ void stream_chunk(const unsigned (&ka)[4], unsigned va0, unsigned va1, const typename VecOf<T>::v8 (&qf)[4],
-                                             f32x16 (&o)[2], float& m_run, float& l_part, float c, int lim) {
+// MASK: 0 none, 1 the last tile only, 2 every tile (causal).  FIRST: the block's first chunk.
+// The reference maximum is LAZY (round 3, third step; profiles/r03_attention_lazy.txt): the kernel's time follows its instruction count, so
+// this form removes vector work instead of moving it:
+//   * Q is pre-multiplied by scale * log2(e) once per query block, so a score is already an exp2 argument;
+//   * the subtraction of the row's reference maximum is done BY THE MFMA: the S accumulators start from -m_ref (`negm`, 16 registers that
+//     change only when m_ref does) instead of 0, the matrix pipe delivers S' = S - m_ref;
+//   * m_ref is the maximum of the FIRST chunk (accumulators from 0, m_ref := chunk maximum) and moves only when a later chunk exceeds it
+//     by more than LAZY_THR (2^8: probabilities stay <= 256, exact in fp32 sums, far inside fp16's range) for some query of the wave - a
+//     wave-uniform, rarely taken branch that rescales O and the row sum; every other chunk is max3 -> exp2 -> add -> convert, with no
+//     fma and no rescale of O (190 vector instructions per chunk against 227).
+// The result is softmax(S) V all the same: numerator and denominator carry the same factor 2^(m_true - m_ref).  kernel_check's and
+// tests/test_gpu_parity.py's spiked cases put maxima into later chunks, above and below the threshold (guide rule 26).
+constexpr float LAZY_THR = 8.0f;
+#if defined(LECLIP_ATTN_PRIO_M)     // experiment: the wave in its matrix phases outranks its SIMD partner
+#define LAZY_PRIO_M() __builtin_amdgcn_s_setprio(1)
+#define LAZY_PRIO_V() __builtin_amdgcn_s_setprio(0)
+#elif defined(LECLIP_ATTN_PRIO_V)   // experiment: the wave in its vector phase outranks its SIMD partner
+#define LAZY_PRIO_M() __builtin_amdgcn_s_setprio(0)
+#define LAZY_PRIO_V() __builtin_amdgcn_s_setprio(1)
+#else
+#define LAZY_PRIO_M() do { } while (0)
+#define LAZY_PRIO_V() do { } while (0)
+#endif
+template <typename T, int NT, int MASK, bool FIRST>
+__device__ __forceinline__ void stream_chunk_lazy(const unsigned (&ka)[4], unsigned va0, unsigned va1, const typename VecOf<T>::v8 (&qf)[4],
+                                                  f32x16 (&o)[2], f32x16& negm, float& m_ref, float& l_part, int lim) {
     typedef typename VecOf<T>::v8 v8;
-    constexpr int KR = 8, KA = KR - 1, VR = 4, VA = VR - 1, NST = 4 * NT, NPV = 2 * NT;   // (ring depths 4 / 3 and 6 / 3 measure the same)
+    constexpr int KR = 8, KA = KR - 1, VR = 4, VA = VR - 1, NST = 4 * NT, NPV = 2 * NT;
     f32x16 sc[NT];
     attn_i32x4 kr[KR];
     attn_i32x2 vr[VR][4];   // [PV step % VR][d block * 2 + key half]
@@ -438,9 +460,9 @@ __device__ __forceinline__ void stream_chunk(const unsigned (&ka)[4], unsigned v
     _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) _Pragma("unroll") for (int u_ = 0; u_ < 2; ++u_)                            \
         asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(vr[(step) % VR][i_ * 2 + u_]) : "v"(i_ ? va1 : va0),           \
                      "n"((((step) >> 1) * 32 + 16 * ((step) & 1) + 8 * u_) * 128))
-    // s_waitcnt lgkmcnt(n) with the registers it releases as in/out operands: nothing that reads them can be scheduled above it
 #define SK_WAIT(n, reg) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(reg) : "n"(n))
-    // ---- S^T = K . Q^T.  DS operations return in order: a read has arrived once at most the reads issued after it are outstanding.
+    // ---- S' = K . Q'^T - m_ref
+    LAZY_PRIO_M();
 #pragma unroll
     for (int st = 0; st < KA && st < NST; ++st) SK_ISSUE(st);
 #pragma unroll
@@ -460,18 +482,22 @@ __device__ __forceinline__ void stream_chunk(const unsigned (&ka)[4], unsigned v
         static_assert(KA <= 7, "wait table");
         const v8 kf = __builtin_bit_cast(v8, kr[st % KR]);
         if (s == 0) {
-            const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            sc[kt] = mfma_32x32x16(kf, qf[s], z);
+            if constexpr (FIRST) {
+                const f32x16 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                sc[kt] = mfma_32x32x16(kf, qf[s], z);
+            } else {
+                sc[kt] = mfma_32x32x16(kf, qf[s], negm);
+            }
         } else {
             sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // the first V^T fragments travel under the softmax arithmetic
 #pragma unroll
     for (int st = 0; st < VA && st < NPV; ++st) SV_ISSUE(st);
-    // ---- mask, running maximum
-    float mx = m_run;
+    // ---- mask, chunk maximum (relative to m_ref unless FIRST)
+    LAZY_PRIO_V();
+    float mx = -3.0e38f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt) {
         if (MASK == 2 || (MASK == 1 && kt == NT - 1)) {
@@ -482,34 +508,41 @@ __device__ __forceinline__ void stream_chunk(const unsigned (&ka)[4], unsigned v
         for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sc[kt][r]), sc[kt][r + 1]);   // (v_max3_f32)
     }
     mx = lane32_max(mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - mx) * c);   // first chunk: exp2(-huge) = 0
-    m_run = mx;
-    const f32x2 c2 = {c, c}, nmb2 = {-mx * c, -mx * c};
-    f32x2 sum2 = {0.f, 0.f};
+    if constexpr (FIRST) {
+        m_ref = mx;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] -= mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -mx;
+    } else if (__builtin_amdgcn_ballot_w64(mx > LAZY_THR) != 0) {   // rare: some query's maximum moved by more than 2^LAZY_THR
+        const float delta = fmaxf(mx, 0.f);
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        m_ref += delta;
+        l_part *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[kt][r] -= delta;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = -m_ref;
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            const f32x2 x = {sc[kt][r], sc[kt][r + 1]};
-            const f32x2 e = __builtin_elementwise_fma(x, c2, nmb2);
-            f32x2 pv;
-            pv[0] = __builtin_amdgcn_exp2f(e[0]);   // arguments are <= 0; masked keys: exp2(-huge) = exactly 0
-            pv[1] = __builtin_amdgcn_exp2f(e[1]);
-            sc[kt][r] = pv[0];
-            sc[kt][r + 1] = pv[1];
-            sum2 += pv;
+        for (int r = 0; r < 16; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sc[kt][r]);   // masked keys: exp2(-huge) = exactly 0
+            sc[kt][r] = pv;
+            ps[r & 3] += pv;
         }
-    l_part = fmaf(l_part, alpha, sum2[0] + sum2[1]);
-    const f32x2 a2 = {alpha, alpha};
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-            f32x2 t = {o[i][r], o[i][r + 1]};
-            t *= a2;
-            o[i][r] = t[0];
-            o[i][r + 1] = t[1];
-        }
+    l_part += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    LAZY_PRIO_M();
     // ---- O^T += V^T . P^T
 #pragma unroll
     for (int st = 0; st < NPV; ++st) {
@@ -605,6 +638,14 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     v8 qf[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, q0[s]);
+    // Q' = Q * scale * log2(e), rounded to the operand type once per query block: the MFMA then delivers exp2 arguments
+    auto prescale_q = [&](v8 (&q)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[s][j] = (T)((float)q[s][j] * a.scale_log2e);
+    };
+    prescale_q(qf);
     ASTAMP(1);
     ASTAMP(2);
 
@@ -619,14 +660,19 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     for (int i = 0; i < 2; ++i)
         vb[i] = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) +
                                                                                      32 * dgrp + 8 * (li & 3));
-    const float c = a.scale_log2e;
     const int nfull = CAUSAL ? 0 : a.T >> 7;                  // chunks whose 128 keys are all valid (image tower: no mask at all)
     const int tail_keys = a.T - (nfull << 7);                 // 0 .. 127 keys in the last, partial chunk
     T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
-    for (int qb = wave; qb < nqb; qb += 8) {
-        const bool has_next = qb + 8 < nqb;
+#ifdef LECLIP_ATTN_ONEWAVE   // experiment (timing of ONE active wave per SIMD, same code): waves 4 .. 7 stage K / V and then idle
+    constexpr int QSTEP = 4;
+    if (wave >= 4) return;
+#else
+    constexpr int QSTEP = 8;
+#endif
+    for (int qb = wave; qb < nqb; qb += QSTEP) {
+        const bool has_next = qb + QSTEP < nqb;
         v8 qn[4];
-        if (has_next) attn_load_q<T>(a, base, qb + 8, lane, qn);
+        if (has_next) attn_load_q<T>(a, base, qb + QSTEP, lane, qn);
         const int qi = qb * 32 + fr;
         const int qrow = qi < a.T ? qi : a.T - 1;
         float m_run = -3.0e38f, l_part = 0.f;
@@ -635,29 +681,38 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
-        auto chunk_at = [&](int key0, auto nt, auto mask, int klimit) {
+        f32x16 negm;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) negm[r] = 0.f;
+        auto chunk_at = [&](int key0, auto nt, auto mask, auto first, int klimit) {
             unsigned ka[4];
 #pragma unroll
             for (int s = 0; s < 4; ++s) ka[s] = ka0[s] + key0 * 128;
-            stream_chunk<T, decltype(nt)::value, decltype(mask)::value>(ka, vb[0] + key0 * 128, vb[1] + key0 * 128, qf, o, m_run, l_part, c,
-                                                                          klimit - key0 - 4 * fh);
+            stream_chunk_lazy<T, decltype(nt)::value, decltype(mask)::value, decltype(first)::value != 0>(
+                ka, vb[0] + key0 * 128, vb[1] + key0 * 128, qf, o, negm, m_run, l_part, klimit - key0 - 4 * fh);
         };
-        auto tail_at = [&](int key0, int keys, auto mask, int klimit) {   // a chunk with 1 .. 128 keys that may hold valid ones
-            const int nt = (keys + 31) >> 5;                             // wave-uniform
-            if (nt == 1) chunk_at(key0, IntC<1>{}, mask, klimit);
-            else if (nt == 2) chunk_at(key0, IntC<2>{}, mask, klimit);
-            else if (nt == 3) chunk_at(key0, IntC<3>{}, mask, klimit);
-            else chunk_at(key0, IntC<4>{}, mask, klimit);
+        auto tail_at = [&](int key0, int keys, auto mask, auto first, int klimit) {   // a chunk with 1 .. 128 keys that may hold valid ones
+            const int nt = (keys + 31) >> 5;                                         // wave-uniform
+            if (nt == 1) chunk_at(key0, IntC<1>{}, mask, first, klimit);
+            else if (nt == 2) chunk_at(key0, IntC<2>{}, mask, first, klimit);
+            else if (nt == 3) chunk_at(key0, IntC<3>{}, mask, first, klimit);
+            else chunk_at(key0, IntC<4>{}, mask, first, klimit);
         };
         if constexpr (!CAUSAL) {
-            for (int ch = 0; ch < nfull; ++ch) chunk_at(ch << 7, IntC<4>{}, IntC<0>{}, a.T - 1);
-            if (tail_keys > 0) tail_at(nfull << 7, tail_keys, IntC<1>{}, a.T - 1);
+            if (nfull > 0) {
+                chunk_at(0, IntC<4>{}, IntC<0>{}, IntC<1>{}, a.T - 1);
+                for (int ch = 1; ch < nfull; ++ch) chunk_at(ch << 7, IntC<4>{}, IntC<0>{}, IntC<0>{}, a.T - 1);
+                if (tail_keys > 0) tail_at(nfull << 7, tail_keys, IntC<1>{}, IntC<0>{}, a.T - 1);
+            } else {
+                tail_at(0, tail_keys, IntC<1>{}, IntC<1>{}, a.T - 1);
+            }
         } else {
             // causal: keys 0 .. qrow; the block's last query is min(qb * 32 + 31, T - 1) (wave-uniform bound on the chunks visited)
             const int last_q = qb * 32 + 31 < a.T - 1 ? qb * 32 + 31 : a.T - 1;
-            for (int key0 = 0; key0 <= last_q; key0 += 128) {
+            tail_at(0, last_q + 1 < 128 ? last_q + 1 : 128, IntC<2>{}, IntC<1>{}, qrow);
+            for (int key0 = 128; key0 <= last_q; key0 += 128) {
                 const int keys = last_q + 1 - key0 < 128 ? last_q + 1 - key0 : 128;
-                tail_at(key0, keys, IntC<2>{}, qrow);
+                tail_at(key0, keys, IntC<2>{}, IntC<0>{}, qrow);
             }
         }
         ASTAMP(3 + 2 * (qb >> 3));
@@ -666,6 +721,7 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
         if (has_next) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+            prescale_q(qf);
         }
         const float inv = 1.0f / lane32_sum(l_part);
         attn_store_block<T>(o, inv, obase + (int64_t)qi * a.ld_out, fh, qi < a.T);
@@ -680,6 +736,298 @@ extern "C" int leclip_attn_stamps_read(unsigned long long* host, size_t n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_attn_stamps), n * sizeof(unsigned long long));
 }
 #endif
+
+#ifdef LECLIP_ATTN_TILE   // experiment, not in the product library (make variant ... DEFS=-DLECLIP_ATTN_TILE): measured SLOWER, see below
+// ---------------------------------------------------------------- tile-pipelined kernel for long sequences (EXPERIMENT, measured slower)
+// Round 3, last step; profiles/r03_attention_lazy.txt.  What the stream kernel above measured: with one of its two waves per SIMD idle
+// it takes 8 % longer, not 100 % - two waves that each run matrix phase -> vector phase -> matrix phase hardly overlap on a SIMD.  This
+// kernel tests the other way to overlap them, ONE wave's own in-order stream (an MFMA holds the issue port for 8 of its 32 cycles, independent
+// vector instructions behind it issue meanwhile - MI355X_MICROARCH.md, cycle constants):
+//   * NW = 4 or 8 waves; K and V of the head in LDS as before (T <= 640);
+//   * a wave walks its 32-query block in KEY TILES of 32, software-pipelined in program order: group t issues the S MFMAs of tile
+//     t + 1 and the PV MFMAs of tile t - 1 and, between them, the softmax arithmetic of tile t (independent of both), and requests the K
+//     fragments of tile t + 2 / the V^T fragments of tile t right behind the MFMAs whose operands they replace - a whole group ahead
+//     of their use, no per-MFMA waits (the compiler's counted lgkmcnt);
+//   * the softmax of a tile is exp2 -> add -> convert and nothing else: Q pre-multiplied, S accumulators from -m_ref, m_ref set by tile
+//     0 (exactly), and a tile whose probabilities sum past 2^12 (or are not finite) for some query of the wave ends the lazy walk: the
+//     rest of the block runs the exact recurrence tile by tile (one-way control flow: no register copies on the fast path).
+// The steady-state group compiles as intended (8 MFMAs, 16 v_exp, 16 adds, 8 conversions, 12 LDS reads, no moves, no spills), results
+// pass kernel_check incl. the spiked cases - and it is SLOWER: ViT-L/14@336 B = 128 f16 412 us with 4 waves (one per SIMD), 361 us with
+// 8, against 336 us for attn_stream_kernel on the same box.  A tile costs ~850 cycles for one wave alone (75 instructions, 256 cycles
+// of MFMA): the time of these kernels follows the number of instructions a SIMD issues (3.7 - 4.8 cycles each with two waves), in
+// every arrangement tried.  Non-causal only.  Not in the product library.
+__device__ __forceinline__ attn_i32x4 lds_ld128(const char* p) {
+    return *(const __attribute__((address_space(3))) attn_i32x4*)LDS_PTR(p);
+}
+
+template <typename T>
+struct TileState {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    f32x16 sc[2];        // scores of tiles t (softmax in progress) and t + 1 (MFMAs in progress), by tile parity
+    v8 pk[2][2];         // probabilities of a tile as MFMA B operands, [tile parity][16-key step]
+    v8 kf[4];            // K fragments of the next S tile, [k-step]; re-requested right behind the MFMAs that read them
+    v4 vf[2][4];         // V^T fragments of the next PV tile, [16-key step][d block * 2 + key half]; the same
+    f32x16 o[2];
+    f32x16 negm;
+    float m_ref, l_part;
+};
+
+template <typename T>
+__device__ __forceinline__ void tile_read_k(TileState<T>& st, const char* const (&kA)[4], int tile) {
+    typedef typename VecOf<T>::v8 v8;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) st.kf[s] = __builtin_bit_cast(v8, lds_ld128(kA[s] + tile * 4096));
+}
+template <typename T>
+__device__ __forceinline__ void tile_read_v(TileState<T>& st, const char* const (&vB)[2], int tile) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) st.vf[s2][i * 2 + u] = lds_read_tr16((const T*)(vB[i] + (tile * 32 + 16 * s2 + 8 * u) * 128));
+}
+// O^T += V^T . P^T of one tile: V^T fragments in st.vf, probabilities in st.pk[PAR]
+template <typename T, int PAR>
+__device__ __forceinline__ void tile_pv(TileState<T>& st) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef __attribute__((ext_vector_type(2))) int i32x2;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const i32x2 lo = __builtin_bit_cast(i32x2, st.vf[s2][i * 2]), hi = __builtin_bit_cast(i32x2, st.vf[s2][i * 2 + 1]);
+            attn_i32x4 w;
+            w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
+            st.o[i] = mfma_32x32x16(__builtin_bit_cast(v8, w), st.pk[PAR][s2], st.o[i]);
+        }
+}
+
+// One tile with the exact recurrence (S from zero accumulators, row maximum, m_ref := max(m_ref, tile maximum), O and the row sum
+// rescaled, probabilities into st.pk[0]): the block's first tile (FIRST: nothing to rescale yet) and the tiles of a block after its
+// lazy walk was abandoned.
+template <typename T, bool FIRST>
+__device__ __forceinline__ void tile_exact(TileState<T>& st, const char* const (&kA)[4], const typename VecOf<T>::v8 (&qf)[4],
+                                           int tile, bool masked, int lim) {
+    typedef typename VecOf<T>::v8 v8;
+    f32x16 sr = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sr = mfma_32x32x16(__builtin_bit_cast(v8, lds_ld128(kA[s] + tile * 4096)), qf[s], sr);
+    if (masked) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sr[r] = lim >= (r & 3) + 8 * (r >> 2) ? sr[r] : -3.0e38f;
+    }
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sr[r]), sr[r + 1]);
+    mx = lane32_max(mx);
+    const float mnew = FIRST ? mx : fmaxf(st.m_ref, mx);
+    if constexpr (!FIRST) {
+        const float alpha = __builtin_amdgcn_exp2f(st.m_ref - mnew);   // <= 1, the same in both lanes of a query
+        st.l_part *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[i][r] *= alpha;
+    }
+    st.m_ref = mnew;
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(sr[r] - mnew);   // masked keys: exp2(-huge) = exactly 0
+        sr[r] = pv;
+        ps[r & 3] += pv;
+    }
+    st.l_part += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st.pk[0][0][j] = (T)sr[j]; st.pk[0][1][j] = (T)sr[8 + j]; }
+}
+
+constexpr float TILE_SUM_MAX = 4096.0f;   // a tile's 16 probabilities per lane may sum to this before the lazy walk is abandoned
+
+// Group t (PAR = t & 1): S MFMAs of tile t + 1, K reads of tile t + 2, PV MFMAs of tile t - 1, V^T reads of tile t, softmax arithmetic
+// of tile t.  HAS_S / HAS_K: tiles t + 1 / t + 2 exist; MASKED: tile t is the last one (keys past T).  Returns this lane's sum of tile t's
+// probabilities, NOT yet added to the row sum: when it passes TILE_SUM_MAX (or is not finite) for some query of the wave the caller
+// leaves the lazy walk and tile t is recomputed exactly.
+template <typename T, int PAR, bool HAS_S, bool HAS_K, bool MASKED>
+__device__ __forceinline__ float tile_group(TileState<T>& st, const char* const (&kA)[4], const char* const (&vB)[2],
+                                           const typename VecOf<T>::v8 (&qf)[4], int t, int lim_last) {
+    constexpr int Q = PAR ^ 1;
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (HAS_S) {   // S' of tile t + 1 from -m_ref (K fragments requested a group ago)
+        st.sc[Q] = mfma_32x32x16(st.kf[0], qf[0], st.negm);
+#pragma unroll
+        for (int s = 1; s < 4; ++s) st.sc[Q] = mfma_32x32x16(st.kf[s], qf[s], st.sc[Q]);
+    }
+    if constexpr (HAS_K) tile_read_k<T>(st, kA, t + 2);
+    tile_pv<T, Q>(st);       // tile t - 1 (V^T fragments requested a group ago)
+    tile_read_v<T>(st, vB, t);
+    // softmax arithmetic of tile t: exp2, sum, convert
+    if constexpr (MASKED) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.sc[PAR][r] = lim_last >= (r & 3) + 8 * (r >> 2) ? st.sc[PAR][r] : -3.0e38f;
+    }
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+    f32x16 pr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        pr[r] = __builtin_amdgcn_exp2f(st.sc[PAR][r]);   // masked keys: exp2(-huge) = exactly 0
+        ps[r & 3] += pr[r];
+    }
+    const float tsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { st.pk[PAR][0][j] = (T)pr[j]; st.pk[PAR][1][j] = (T)pr[8 + j]; }
+    // 1 MFMA : 2 transcendental : 3 other vector instructions, the LDS reads behind the MFMAs whose operands they replace
+    if constexpr (HAS_S) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+        }
+    }
+    if constexpr (HAS_K) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x400, HAS_S ? 2 : 4, 0);
+        __builtin_amdgcn_sched_group_barrier(0x002, HAS_S ? 3 : 6, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+    return tsum;
+}
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void attn_tile_kernel(AttnArgs a, int TP) {
+    typedef typename VecOf<T>::v8 v8;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // K [TP][128 B] | V [TP][128 B]
+    char* sK = smem;
+    char* sV = smem + TP * 128;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
+    const int d_model = a.heads * 64;
+    const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5;
+    const int ntiles = TP >> 5;
+    // the wave's first query block, then K and V by LDS-DMA (8 rows x 128 B per piece, every piece of the head in flight)
+    attn_i32x4 q0[4];
+    {
+        const int qi = wave * 32 + (lane & 31);
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q0[s]) : "v"(qp), "n"(s * 32));
+    }
+    const int npieces = TP >> 3;
+    for (int isv = 0; isv < 2; ++isv)
+        for (int piece = wave; piece < npieces; piece += NW) {
+            const int row = piece * 8 + (lane >> 3);
+            const int p = lane & 7;
+            const int cc = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+            const int grow = row < a.T ? row : a.T - 1;
+            const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + cc * 8;
+            __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]) : : "memory");
+    __builtin_amdgcn_s_barrier();
+    v8 qf[4];
+    auto prescale_q = [&](v8 (&q)[4]) {   // Q' = Q * scale * log2(e), rounded to the operand type once per query block
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q[s][j] = (T)((float)q[s][j] * a.scale_log2e);
+    };
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, q0[s]);
+    prescale_q(qf);
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int li = lane & 15, dgrp = (lane >> 4) & 1;
+    const char* kA[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kA[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
+    const char* vB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) vB[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
+    const int lim_last = a.T - 1 - (ntiles - 1) * 32 - 4 * fh;   // last valid key, relative to the last tile's lane origin
+    T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
+    for (int qb = wave; qb < nqb; qb += NW) {
+        const bool has_next = qb + NW < nqb;
+        v8 qn[4];
+        if (has_next) attn_load_q<T>(a, base, qb + NW, lane, qn);
+        const int qi = qb * 32 + fr;
+        TileState<T> st;
+        st.m_ref = -3.0e38f;
+        st.l_part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) st.o[i][r] = 0.f;
+        // prologue: tile 0 exactly (sets m_ref), S' of tile 1, the operand reads of group 1
+        tile_exact<T, true>(st, kA, qf, 0, ntiles == 1, lim_last);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st.negm[r] = -st.m_ref;
+        tile_read_v<T>(st, vB, 0);
+        if (ntiles > 1) {
+            tile_read_k<T>(st, kA, 1);
+            st.sc[1] = mfma_32x32x16(st.kf[0], qf[0], st.negm);
+#pragma unroll
+            for (int s = 1; s < 4; ++s) st.sc[1] = mfma_32x32x16(st.kf[s], qf[s], st.sc[1]);
+            if (ntiles > 2) tile_read_k<T>(st, kA, 2);
+        }
+        // groups 1 .. ntiles - 1: the steady state while tile t + 2 exists, then the two tail forms.  `lazy` turns false when group t
+        // found tile t out of range (its probabilities are then NOT in the row sum): the exact loop below takes over at tile t.
+        int t = 1;
+        bool lazy = true;
+#define LECLIP_TILE_GROUP(PAR, HS, HK, MK)                                                         \
+        do {                                                                                       \
+            const float ts_ = tile_group<T, PAR, HS, HK, MK>(st, kA, vB, qf, t, lim_last);         \
+            lazy = __builtin_amdgcn_ballot_w64(!(ts_ <= TILE_SUM_MAX)) == 0;                       \
+            if (lazy) { st.l_part += ts_; ++t; }                                                   \
+        } while (0)
+        while (lazy && t + 3 < ntiles) {          // t odd here: two steady groups per trip
+            LECLIP_TILE_GROUP(1, true, true, false);
+            if (!lazy) break;
+            LECLIP_TILE_GROUP(0, true, true, false);
+        }
+        while (lazy && t < ntiles) {              // at most three more groups, either parity
+            const int left = ntiles - 1 - t;      // tiles after t
+            if (t & 1) {
+                if (left >= 2) LECLIP_TILE_GROUP(1, true, true, false);
+                else if (left == 1) LECLIP_TILE_GROUP(1, true, false, false);
+                else LECLIP_TILE_GROUP(1, false, false, true);
+            } else {
+                if (left >= 2) LECLIP_TILE_GROUP(0, true, true, false);
+                else if (left == 1) LECLIP_TILE_GROUP(0, true, false, false);
+                else LECLIP_TILE_GROUP(0, false, false, true);
+            }
+        }
+#undef LECLIP_TILE_GROUP
+        if (lazy) {
+            // PV of the last tile (its V^T fragments were requested by its own group - or by the prologue)
+            if ((ntiles - 1) & 1) tile_pv<T, 1>(st); else tile_pv<T, 0>(st);
+        } else {
+            // Rare: some query's scores in tile t are far above its reference maximum.  O and the row sum hold tiles 0 .. t - 1 (group t has
+            // issued PV of tile t - 1 before its check); the rest of the block runs the exact recurrence, one tile at a time.
+            for (; t < ntiles; ++t) {
+                tile_exact<T, false>(st, kA, qf, t, t == ntiles - 1, lim_last);
+                tile_read_v<T>(st, vB, t);
+                tile_pv<T, 0>(st);
+            }
+        }
+        // the next block's Q (requested a whole block ago) moves in before this block's stores
+        if (has_next) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) qf[s] = qn[s];
+            prescale_q(qf);
+        }
+        const float inv = 1.0f / lane32_sum(st.l_part);
+        attn_store_block<T>(st.o, inv, obase + (int64_t)qi * a.ld_out, fh, qi < a.T);
+    }
+}
+#endif   // LECLIP_ATTN_TILE
 
 // ---------------------------------------------------------------- fp32 validation kernel
 // One workgroup per (batch, head), K and V in LDS as fp32 (rows padded to 65 floats), one query row per wave at
@@ -778,6 +1126,17 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
         if (a.causal) {
             leclip_set_max_lds(attn_stream_kernel<T, true>, STREAM_TMAX * 256, attr_set_c);
             hipLaunchKernelGGL((attn_stream_kernel<T, true>), dim3(grid), dim3(512), TP * 256, s, a, TP);
+#ifdef LECLIP_ATTN_TILE
+        } else if (true) {
+            static bool attr_set_t[LECLIP_MAX_DEVICES] = {};
+            const int TP32 = (a.T + 31) & ~31;
+#ifndef LECLIP_ATTN_TILE_NW
+#define LECLIP_ATTN_TILE_NW 8
+#endif
+            leclip_set_max_lds((attn_tile_kernel<T, LECLIP_ATTN_TILE_NW>), STREAM_TMAX * 256, attr_set_t);
+            hipLaunchKernelGGL((attn_tile_kernel<T, LECLIP_ATTN_TILE_NW>), dim3(grid), dim3(LECLIP_ATTN_TILE_NW * 64), TP32 * 256, s, a, TP32);
+            return leclip_check_launch("attn_tile_kernel");
+#endif
         } else {
             leclip_set_max_lds(attn_stream_kernel<T, false>, STREAM_TMAX * 256, attr_set);
             hipLaunchKernelGGL((attn_stream_kernel<T, false>), dim3(grid), dim3(512), TP * 256, s, a, TP);

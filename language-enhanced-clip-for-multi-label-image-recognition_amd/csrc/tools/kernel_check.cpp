@@ -78,9 +78,22 @@ static void check_gemm(int64_t M, int N, int K, int ab, int resdt, int outdt, in
     if (!ok) g_fail++;
 }
 
-static void check_attn(int B, int T, int heads, int dt, int causal) {
+// spike > 0: some key rows are set to multiples of query rows, so that a query's running maximum jumps in a LATER key chunk - by far
+// more than the streaming kernel's lazy-reference threshold (factor 3: +35 in log2 units) and by less than it (factor 0.6) - the
+// data-dependent rescale branch and the stale-reference path both run (cdna_hip_programming.md rule 26).
+static void check_attn(int B, int T, int heads, int dt, int causal, int spike = 0) {
     const int d = heads * 64;
     auto Q = randn((size_t)B * T * 3 * d);
+    if (spike) {
+        for (int b = 0; b < B; ++b) for (int h = 0; h < heads; ++h) {
+            struct P { int q, k; float f; } pairs[] = {{5, 140, 3.0f}, {40, 300, 3.0f}, {41, 520, 0.6f}, {T - 3, T - 2, 3.0f}, {T - 1, 130, 0.6f},
+                                                       {200, 131, 3.0f}, {200, 400, 4.0f}, {333, T - 1, 3.0f}, {64, 64, 3.0f}, {65, 257, 2.0f}};
+            for (auto& pr : pairs) {
+                if (pr.q >= T || pr.k >= T || pr.q < 0 || pr.k < 0) continue;
+                for (int e = 0; e < 64; ++e) Q[((size_t)b * T + pr.k) * 3 * d + d + h * 64 + e] = pr.f * Q[((size_t)b * T + pr.q) * 3 * d + h * 64 + e];
+            }
+        }
+    }
     auto Qp = pack(Q, dt);
     Buf dQ(Qp.size()), dO((size_t)B * T * d * (dt == LECLIP_F32 ? 4 : 2));
     dQ.up(Qp.data());
@@ -111,7 +124,7 @@ static void check_attn(int B, int T, int heads, int dt, int causal) {
     }
     double tol = dt == LECLIP_F32 ? 2e-5 : (dt == LECLIP_BF16 ? 2.5e-2 : 4e-3);
     bool ok = maxerr <= tol && maxerr == maxerr;
-    printf("%s attn B=%d T=%d heads=%d %s causal=%d: maxerr %.3e (tol %.1e)\n", ok ? "ok  " : "FAIL", B, T, heads, dtn(dt), causal, maxerr, tol);
+    printf("%s attn B=%d T=%d heads=%d %s causal=%d spike=%d: maxerr %.3e (tol %.1e)\n", ok ? "ok  " : "FAIL", B, T, heads, dtn(dt), causal, spike, maxerr, tol);
     if (!ok) g_fail++;
 }
 
@@ -190,6 +203,9 @@ static int attn() {
         check_attn(2, 577, 16, dt, 0);     // attn_stream_kernel
         check_attn(1, 640, 3, dt, 0);
         check_attn(1, 300, 2, dt, 1);
+        check_attn(2, 577, 3, dt, 0, 1);   // maxima that jump in later chunks (lazy reference maximum: rescale branch + stale reference)
+        check_attn(1, 600, 2, dt, 1, 1);
+        check_attn(1, 257, 2, dt, 0, 1);
     }
     printf(g_fail ? "FAILED %d checks\n" : "ALL OK\n", g_fail);
     if (g_fail) return 1;

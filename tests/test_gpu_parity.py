@@ -238,7 +238,7 @@ def test_attention(ops, dt, cfg):
 @pytest.mark.parametrize("cfg", [(1, 577, 3, False), (2, 640, 1, False), (1, 257, 2, False), (1, 225, 1, False), (1, 512, 1, False), (1, 300, 2, True),
                                  (1, 385, 1, True), (1, 640, 1, True)])
 def test_attention_long(ops, dt, cfg):
-    """225 .. 640 tokens run the streaming kernel (attn_stream_kernel: 128-key chunks, online softmax): whole chunks only (512), a last
+    """225 .. 640 tokens run the streaming kernel (attn_stream_kernel: 128-key chunks, online softmax with a lazy reference maximum): whole chunks only (512), a last
     chunk of one key (257, 385), of one tile plus one key (225 -> 97 keys in chunk 1), of 65 keys (577: ViT-L/14@336), the full 640, and
     the causal form, whose chunks are masked per element and end at the query block's diagonal."""
     b, t, h, causal = cfg
@@ -252,6 +252,32 @@ def test_attention_long(ops, dt, cfg):
     y = ops.attention(qkv.to(DEV), b, t, h, causal)
     np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-5, 4e-3, 2.5e-2), rtol=0)
     assert torch.equal(y, ops.attention(qkv.to(DEV), b, t, h, causal))     # deterministic
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 577, 3, False), (1, 600, 2, True), (1, 257, 2, False), (1, 640, 1, False)])
+def test_attention_long_late_maxima(ops, dt, cfg):
+    """The streaming kernel keeps a LAZY reference maximum per query (set by the first 128-key chunk; the S accumulators start from
+    -m_ref, a later chunk moves it only when it exceeds it by more than 2^8).  Key rows that are multiples of query rows put a query's
+    maximum into a LATER chunk: far above the threshold (factor 3 - 4: the rescale branch), below it (0.6: the stale reference is kept),
+    in the last tile, in the chunk after the first, and twice for one query."""
+    b, t, h, causal = cfg
+    d = 64 * h
+    x = _rand((b * t, 3 * d), 17).reshape(b, t, 3, h, 64).clone()
+    pairs = [(5, 140, 3.0), (40, 300, 3.0), (41, 520, 0.6), (t - 3, t - 2, 3.0), (t - 1, 130, 0.6), (200, 131, 3.0), (200, 400, 4.0),
+             (333, t - 1, 3.0), (64, 64, 3.0), (65, 257, 2.0), (130, 129, 1.5)]
+    for qi, ki, f in pairs:
+        if 0 <= qi < t and 0 <= ki < t:
+            x[:, ki, 1] = f * x[:, qi, 0]
+    qkv = x.reshape(b * t, 3 * d).to(dt)
+    q, k, v = [z.reshape(b, t, h, 64).transpose(1, 2).double() for z in qkv.float().split(d, dim=-1)]
+    s = q @ k.transpose(-1, -2) * 0.125
+    if causal:
+        s = s + torch.triu(torch.full((t, t), float("-inf"), dtype=torch.float64), 1)
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(b * t, d)
+    y = ops.attention(qkv.to(DEV), b, t, h, causal)
+    assert bool(torch.isfinite(y.float()).all())
+    np.testing.assert_allclose(y.double().cpu().numpy(), ref.numpy(), atol=_tol(dt, 2e-5, 4e-3, 2.5e-2), rtol=0)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
