@@ -5,5 +5,5 @@ L=language-enhanced-clip-for-multi-label-image-recognition_amd/lib/exp
 mkdir -p gpurun_out
 for v in "$@"; do
   echo "== $v"
-  timeout -k 10 400 $L/kernel_check_$v attn 2>&1 | grep -v "^ok " || exit 1
+  timeout -k 10 400 $L/kernel_check_$v attn > gpurun_out/.ab_attn_$v.log 2>&1; rc=$?; grep -v "^ok " gpurun_out/.ab_attn_$v.log; [ $rc -eq 0 ] || { echo "variant $v failed (rc $rc): stopping"; exit 1; }
 done
