@@ -379,7 +379,7 @@ int main(int argc, char** argv) {
         check_attn(2, 197, 3, dt, 0);
         check_attn(3, 224, 2, dt, 0);
         check_attn(2, 200, 2, dt, 1);
-        if (dt != LECLIP_F32) { check_attn(1, 577, 2, dt, 0); check_attn(1, 300, 1, dt, 1); check_attn(1, 640, 1, dt, 0); }
+        if (dt != LECLIP_F32) { check_attn(1, 577, 2, dt, 0); check_attn(1, 300, 1, dt, 1); check_attn(1, 640, 1, dt, 0); check_attn(1, 577, 2, dt, 0, 1); check_attn(1, 600, 1, dt, 1, 1); }
         check_attn(3, 77, 2, dt, 1);
         check_attn(2, 17, 2, dt, 0);
         check_attn(1, 50, 1, dt, 1);
