@@ -80,6 +80,32 @@ if os.path.isdir(os.path.join(SRC, "pmc_sq_vitl")):
     out["attn_stream_kernel (ViT-L/14@336, B=128)"] = {"SQ": sq_s, "GRBM_GUI_ACTIVE": g_s.get("GRBM_GUI_ACTIVE"),
                                                        "mfma_busy_frac_of_simd_cycles": sq_s.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(g_s.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)}
 
+# instruction-issue counters (profiles/collect_issue.sh: two passes of 8 SQ counters each).  SQ_INSTS_* count wave instructions (SQ_INSTS_VALU includes
+# the MFMAs), SQ_ACTIVE_INST_* / SQ_WAVE_CYCLES count quad-cycles summed over waves, SQ_VALU_MFMA_*_CYCLES count cycles summed over SIMDs.
+if os.path.isdir(os.path.join(SRC, "pmc_issue1")):
+    def issue(sub1, sub2, match):
+        a, n = by_kernel(counters(sub1), match)
+        b, _ = by_kernel(counters(sub2), match)
+        a.update(b)
+        d = {"dispatches_averaged": n, "counters": a}
+        if a.get("SQ_INSTS_VALU"):
+            valu = a["SQ_INSTS_VALU"] - a.get("SQ_INSTS_MFMA", 0)
+            d["derived"] = {
+                "mfma_instructions": a.get("SQ_INSTS_MFMA"), "other_vector_instructions": valu,
+                "lds_instructions": a.get("SQ_INSTS_LDS"), "scalar_instructions": a.get("SQ_INSTS_SALU"), "vmem_instructions": a.get("SQ_INSTS_VMEM"),
+                "vector_issue_cycles_per_vector_instruction_incl_mfma": 4 * a.get("SQ_ACTIVE_INST_VALU", 0) / a["SQ_INSTS_VALU"],
+                "wave_active_fraction": a.get("SQ_ACTIVE_INST_ANY", 0) / max(a.get("SQ_WAVE_CYCLES", 0), 1),
+                "mfma_cycles_with_a_vector_instruction_executing_beside": a.get("SQ_VALU_MFMA_COEXEC_CYCLES", 0) / max(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), 1),
+                "vector_issue_cycles_over_mfma_busy_cycles": 4 * a.get("SQ_ACTIVE_INST_VALU", 0) / max(a.get("SQ_VALU_MFMA_BUSY_CYCLES", 0), 1)}
+        return d
+    out["issue"] = {
+        "qkv GEMM <f16,2,0>": issue("pmc_issue1", "pmc_issue2", GEMM + "IDF16_Li2ELi0"),
+        "c_fc GEMM <f16,2,1>": issue("pmc_issue1", "pmc_issue2", GEMM + "IDF16_Li2ELi1"),
+        "out-proj / c_proj GEMM <f16,1,2>": issue("pmc_issue1", "pmc_issue2", GEMM + "IDF16_Li1ELi2"),
+        "attn_heads_kernel (ViT-B/16, B=256)": issue("pmc_issue1", "pmc_issue2", "attn_heads_kernel")}
+    if os.path.isdir(os.path.join(SRC, "pmc_issue1_vitl")):
+        out["issue"]["attn_stream_kernel (ViT-L/14@336, B=128)"] = issue("pmc_issue1_vitl", "pmc_issue2_vitl", "attn_stream_kernel")
+
 
 # ---- the GEMM family per launch shape, from the per-dispatch kernel trace (the persistent grid is 256 workgroups for every shape, so
 # the shape is told by the kernel flavour and - for <T,1,2>, which serves out-proj and c_proj alternately - by the dispatch order
