@@ -603,23 +603,13 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
     const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
     ASTAMP(0);
     ASTAMP_RT(14);
-    // The wave's first query block is requested first, then K and V by LDS-DMA, every piece (8 rows x 128 B) of the head in flight
-    // at once.  (Starting chunk c of the first query block as soon as the pieces of chunks 0 .. c have landed - pieces issued in
+    // K and V of the head by LDS-DMA, every piece (8 rows x 128 B) in flight at once, then the wave's first query block (below).  (Starting chunk c of the first query block as soon as the pieces of chunks 0 .. c have landed - pieces issued in
     // chunk order, a counted vmcnt and a barrier per chunk - was built and measured 5 % SLOWER: a CU takes the 148 KB of a head in
     // at 13 bytes per cycle whatever the order, the first chunk's pieces land almost as late as the last one's, and the loads then
     // run beside the first block's arithmetic instead of in front of it; profiles/r03_attention_stream.txt.)
     const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5;
     const int nch = TP >> 7;
-    // (inline asm, released by the wait below: the compiler then has no pending load on these registers at the head of the query-block
-    // loop and puts no s_waitcnt vmcnt(0) in front of every block's first MFMA - where it would wait for the NEXT block's Q, just requested)
     attn_i32x4 q0[4];
-    {
-        const int qi = wave * 32 + (lane & 31);
-        const int qrow = qi < a.T ? qi : a.T - 1;
-        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q0[s]) : "v"(qp), "n"(s * 32));
-    }
     for (int ch = 0; ch < nch; ++ch) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -633,7 +623,24 @@ __global__ __launch_bounds__(512, 2) void attn_stream_kernel(AttnArgs a, int TP)
             __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]) : : "memory");
+    // The wave's first Q block: loads AND their wait in ONE asm statement (early-clobber outputs), behind the LDS-DMA issue loop.  Inline
+    // asm so that the compiler has no pending load on these registers at the head of the query-block loop (it would put s_waitcnt
+    // vmcnt(0) in front of every block's first MFMA, where it waits for the NEXT block's Q, just requested); ONE statement so that no
+    // compiler-scheduled instruction can sit between the issue and the wait - an asm load's destination counts as written when its
+    // statement ends, so across compiler code it may be copied, spilled or re-used before the data lands (round 3 issued these loads
+    // in front of the DMA loop and waited behind it: tests/isa_audit.py now checks the shipped code objects for that pattern).  vmcnt
+    // retires in order, so the wait also covers every K / V piece issued above.
+    {
+        const int qi = wave * 32 + (lane & 31);
+        const int qrow = qi < a.T ? qi : a.T - 1;
+        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
+        asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                     "global_load_dwordx4 %1, %4, off offset:32\n\t"
+                     "global_load_dwordx4 %2, %4, off offset:64\n\t"
+                     "global_load_dwordx4 %3, %4, off offset:96\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(q0[0]), "=&v"(q0[1]), "=&v"(q0[2]), "=&v"(q0[3]) : "v"(qp) : "memory");
+    }
     __builtin_amdgcn_s_barrier();
     v8 qf[4];
 #pragma unroll
@@ -737,298 +744,6 @@ extern "C" int leclip_attn_stamps_read(unsigned long long* host, size_t n) {
 }
 #endif
 
-#ifdef LECLIP_ATTN_TILE   // experiment, not in the product library (make variant ... DEFS=-DLECLIP_ATTN_TILE): measured SLOWER, see below
-// ---------------------------------------------------------------- tile-pipelined kernel for long sequences (EXPERIMENT, measured slower)
-// Round 3, last step; profiles/r03_attention_lazy.txt.  What the stream kernel above measured: with one of its two waves per SIMD idle
-// it takes 8 % longer, not 100 % - two waves that each run matrix phase -> vector phase -> matrix phase hardly overlap on a SIMD.  This
-// kernel tests the other way to overlap them, ONE wave's own in-order stream (an MFMA holds the issue port for 8 of its 32 cycles, independent
-// vector instructions behind it issue meanwhile - MI355X_MICROARCH.md, cycle constants):
-//   * NW = 4 or 8 waves; K and V of the head in LDS as before (T <= 640);
-//   * a wave walks its 32-query block in KEY TILES of 32, software-pipelined in program order: group t issues the S MFMAs of tile
-//     t + 1 and the PV MFMAs of tile t - 1 and, between them, the softmax arithmetic of tile t (independent of both), and requests the K
-//     fragments of tile t + 2 / the V^T fragments of tile t right behind the MFMAs whose operands they replace - a whole group ahead
-//     of their use, no per-MFMA waits (the compiler's counted lgkmcnt);
-//   * the softmax of a tile is exp2 -> add -> convert and nothing else: Q pre-multiplied, S accumulators from -m_ref, m_ref set by tile
-//     0 (exactly), and a tile whose probabilities sum past 2^12 (or are not finite) for some query of the wave ends the lazy walk: the
-//     rest of the block runs the exact recurrence tile by tile (one-way control flow: no register copies on the fast path).
-// The steady-state group compiles as intended (8 MFMAs, 16 v_exp, 16 adds, 8 conversions, 12 LDS reads, no moves, no spills), results
-// pass kernel_check incl. the spiked cases - and it is SLOWER: ViT-L/14@336 B = 128 f16 412 us with 4 waves (one per SIMD), 361 us with
-// 8, against 336 us for attn_stream_kernel on the same box.  A tile costs ~850 cycles for one wave alone (75 instructions, 256 cycles
-// of MFMA): the time of these kernels follows the number of instructions a SIMD issues (3.7 - 4.8 cycles each with two waves), in
-// every arrangement tried.  Non-causal only.  Not in the product library.
-__device__ __forceinline__ attn_i32x4 lds_ld128(const char* p) {
-    return *(const __attribute__((address_space(3))) attn_i32x4*)LDS_PTR(p);
-}
-
-template <typename T>
-struct TileState {
-    typedef typename VecOf<T>::v8 v8;
-    typedef typename VecOf<T>::v4 v4;
-    f32x16 sc[2];        // scores of tiles t (softmax in progress) and t + 1 (MFMAs in progress), by tile parity
-    v8 pk[2][2];         // probabilities of a tile as MFMA B operands, [tile parity][16-key step]
-    v8 kf[4];            // K fragments of the next S tile, [k-step]; re-requested right behind the MFMAs that read them
-    v4 vf[2][4];         // V^T fragments of the next PV tile, [16-key step][d block * 2 + key half]; the same
-    f32x16 o[2];
-    f32x16 negm;
-    float m_ref, l_part;
-};
-
-template <typename T>
-__device__ __forceinline__ void tile_read_k(TileState<T>& st, const char* const (&kA)[4], int tile) {
-    typedef typename VecOf<T>::v8 v8;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) st.kf[s] = __builtin_bit_cast(v8, lds_ld128(kA[s] + tile * 4096));
-}
-template <typename T>
-__device__ __forceinline__ void tile_read_v(TileState<T>& st, const char* const (&vB)[2], int tile) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) st.vf[s2][i * 2 + u] = lds_read_tr16((const T*)(vB[i] + (tile * 32 + 16 * s2 + 8 * u) * 128));
-}
-// O^T += V^T . P^T of one tile: V^T fragments in st.vf, probabilities in st.pk[PAR]
-template <typename T, int PAR>
-__device__ __forceinline__ void tile_pv(TileState<T>& st) {
-    typedef typename VecOf<T>::v8 v8;
-    typedef __attribute__((ext_vector_type(2))) int i32x2;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const i32x2 lo = __builtin_bit_cast(i32x2, st.vf[s2][i * 2]), hi = __builtin_bit_cast(i32x2, st.vf[s2][i * 2 + 1]);
-            attn_i32x4 w;
-            w[0] = lo[0]; w[1] = lo[1]; w[2] = hi[0]; w[3] = hi[1];
-            st.o[i] = mfma_32x32x16(__builtin_bit_cast(v8, w), st.pk[PAR][s2], st.o[i]);
-        }
-}
-
-// One tile with the exact recurrence (S from zero accumulators, row maximum, m_ref := max(m_ref, tile maximum), O and the row sum
-// rescaled, probabilities into st.pk[0]): the block's first tile (FIRST: nothing to rescale yet) and the tiles of a block after its
-// lazy walk was abandoned.
-template <typename T, bool FIRST>
-__device__ __forceinline__ void tile_exact(TileState<T>& st, const char* const (&kA)[4], const typename VecOf<T>::v8 (&qf)[4],
-                                           int tile, bool masked, int lim) {
-    typedef typename VecOf<T>::v8 v8;
-    f32x16 sr = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sr = mfma_32x32x16(__builtin_bit_cast(v8, lds_ld128(kA[s] + tile * 4096)), qf[s], sr);
-    if (masked) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sr[r] = lim >= (r & 3) + 8 * (r >> 2) ? sr[r] : -3.0e38f;
-    }
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) mx = fmaxf(fmaxf(mx, sr[r]), sr[r + 1]);
-    mx = lane32_max(mx);
-    const float mnew = FIRST ? mx : fmaxf(st.m_ref, mx);
-    if constexpr (!FIRST) {
-        const float alpha = __builtin_amdgcn_exp2f(st.m_ref - mnew);   // <= 1, the same in both lanes of a query
-        st.l_part *= alpha;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st.o[i][r] *= alpha;
-    }
-    st.m_ref = mnew;
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(sr[r] - mnew);   // masked keys: exp2(-huge) = exactly 0
-        sr[r] = pv;
-        ps[r & 3] += pv;
-    }
-    st.l_part += (ps[0] + ps[1]) + (ps[2] + ps[3]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { st.pk[0][0][j] = (T)sr[j]; st.pk[0][1][j] = (T)sr[8 + j]; }
-}
-
-constexpr float TILE_SUM_MAX = 4096.0f;   // a tile's 16 probabilities per lane may sum to this before the lazy walk is abandoned
-
-// Group t (PAR = t & 1): S MFMAs of tile t + 1, K reads of tile t + 2, PV MFMAs of tile t - 1, V^T reads of tile t, softmax arithmetic
-// of tile t.  HAS_S / HAS_K: tiles t + 1 / t + 2 exist; MASKED: tile t is the last one (keys past T).  Returns this lane's sum of tile t's
-// probabilities, NOT yet added to the row sum: when it passes TILE_SUM_MAX (or is not finite) for some query of the wave the caller
-// leaves the lazy walk and tile t is recomputed exactly.
-template <typename T, int PAR, bool HAS_S, bool HAS_K, bool MASKED>
-__device__ __forceinline__ float tile_group(TileState<T>& st, const char* const (&kA)[4], const char* const (&vB)[2],
-                                           const typename VecOf<T>::v8 (&qf)[4], int t, int lim_last) {
-    constexpr int Q = PAR ^ 1;
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (HAS_S) {   // S' of tile t + 1 from -m_ref (K fragments requested a group ago)
-        st.sc[Q] = mfma_32x32x16(st.kf[0], qf[0], st.negm);
-#pragma unroll
-        for (int s = 1; s < 4; ++s) st.sc[Q] = mfma_32x32x16(st.kf[s], qf[s], st.sc[Q]);
-    }
-    if constexpr (HAS_K) tile_read_k<T>(st, kA, t + 2);
-    tile_pv<T, Q>(st);       // tile t - 1 (V^T fragments requested a group ago)
-    tile_read_v<T>(st, vB, t);
-    // softmax arithmetic of tile t: exp2, sum, convert
-    if constexpr (MASKED) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st.sc[PAR][r] = lim_last >= (r & 3) + 8 * (r >> 2) ? st.sc[PAR][r] : -3.0e38f;
-    }
-    float ps[4] = {0.f, 0.f, 0.f, 0.f};
-    f32x16 pr;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        pr[r] = __builtin_amdgcn_exp2f(st.sc[PAR][r]);   // masked keys: exp2(-huge) = exactly 0
-        ps[r & 3] += pr[r];
-    }
-    const float tsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { st.pk[PAR][0][j] = (T)pr[j]; st.pk[PAR][1][j] = (T)pr[8 + j]; }
-    // 1 MFMA : 2 transcendental : 3 other vector instructions, the LDS reads behind the MFMAs whose operands they replace
-    if constexpr (HAS_S) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x400, 2, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-        }
-    }
-    if constexpr (HAS_K) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x400, HAS_S ? 2 : 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, HAS_S ? 3 : 6, 0);
-    }
-    __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
-    return tsum;
-}
-
-template <typename T, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void attn_tile_kernel(AttnArgs a, int TP) {
-    typedef typename VecOf<T>::v8 v8;
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // K [TP][128 B] | V [TP][128 B]
-    char* sK = smem;
-    char* sV = smem + TP * 128;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int b = blockIdx.x / a.heads, h = blockIdx.x - b * a.heads;
-    const int d_model = a.heads * 64;
-    const T* base = (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
-    const int nqb = ((a.q_rows > 0 ? a.q_rows : a.T) + 31) >> 5;
-    const int ntiles = TP >> 5;
-    // the wave's first query block, then K and V by LDS-DMA (8 rows x 128 B per piece, every piece of the head in flight)
-    attn_i32x4 q0[4];
-    {
-        const int qi = wave * 32 + (lane & 31);
-        const int qrow = qi < a.T ? qi : a.T - 1;
-        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(q0[s]) : "v"(qp), "n"(s * 32));
-    }
-    const int npieces = TP >> 3;
-    for (int isv = 0; isv < 2; ++isv)
-        for (int piece = wave; piece < npieces; piece += NW) {
-            const int row = piece * 8 + (lane >> 3);
-            const int p = lane & 7;
-            const int cc = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
-            const int grow = row < a.T ? row : a.T - 1;
-            const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + cc * 8;
-            __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR((isv ? sV : sK) + piece * 1024), 16, 0, 0);
-        }
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(q0[0]), "+v"(q0[1]), "+v"(q0[2]), "+v"(q0[3]) : : "memory");
-    __builtin_amdgcn_s_barrier();
-    v8 qf[4];
-    auto prescale_q = [&](v8 (&q)[4]) {   // Q' = Q * scale * log2(e), rounded to the operand type once per query block
-#pragma unroll
-        for (int s = 0; s < 4; ++s)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) q[s][j] = (T)((float)q[s][j] * a.scale_log2e);
-    };
-#pragma unroll
-    for (int s = 0; s < 4; ++s) qf[s] = __builtin_bit_cast(v8, q0[s]);
-    prescale_q(qf);
-
-    const int fr = lane & 31, fh = lane >> 5;
-    const int li = lane & 15, dgrp = (lane >> 4) & 1;
-    const char* kA[4];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kA[s] = sK + fr * 128 + (((2 * s + fh) ^ ((fr >> 1) & 7)) << 4);
-    const char* vB[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) vB[i] = sV + (4 * fh + (li >> 2)) * 128 + ((64 * i) ^ (((li >> 3) & 1) << 6)) + 32 * dgrp + 8 * (li & 3);
-    const int lim_last = a.T - 1 - (ntiles - 1) * 32 - 4 * fh;   // last valid key, relative to the last tile's lane origin
-    T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
-    for (int qb = wave; qb < nqb; qb += NW) {
-        const bool has_next = qb + NW < nqb;
-        v8 qn[4];
-        if (has_next) attn_load_q<T>(a, base, qb + NW, lane, qn);
-        const int qi = qb * 32 + fr;
-        TileState<T> st;
-        st.m_ref = -3.0e38f;
-        st.l_part = 0.f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) st.o[i][r] = 0.f;
-        // prologue: tile 0 exactly (sets m_ref), S' of tile 1, the operand reads of group 1
-        tile_exact<T, true>(st, kA, qf, 0, ntiles == 1, lim_last);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) st.negm[r] = -st.m_ref;
-        tile_read_v<T>(st, vB, 0);
-        if (ntiles > 1) {
-            tile_read_k<T>(st, kA, 1);
-            st.sc[1] = mfma_32x32x16(st.kf[0], qf[0], st.negm);
-#pragma unroll
-            for (int s = 1; s < 4; ++s) st.sc[1] = mfma_32x32x16(st.kf[s], qf[s], st.sc[1]);
-            if (ntiles > 2) tile_read_k<T>(st, kA, 2);
-        }
-        // groups 1 .. ntiles - 1: the steady state while tile t + 2 exists, then the two tail forms.  `lazy` turns false when group t
-        // found tile t out of range (its probabilities are then NOT in the row sum): the exact loop below takes over at tile t.
-        int t = 1;
-        bool lazy = true;
-#define LECLIP_TILE_GROUP(PAR, HS, HK, MK)                                                         \
-        do {                                                                                       \
-            const float ts_ = tile_group<T, PAR, HS, HK, MK>(st, kA, vB, qf, t, lim_last);         \
-            lazy = __builtin_amdgcn_ballot_w64(!(ts_ <= TILE_SUM_MAX)) == 0;                       \
-            if (lazy) { st.l_part += ts_; ++t; }                                                   \
-        } while (0)
-        while (lazy && t + 3 < ntiles) {          // t odd here: two steady groups per trip
-            LECLIP_TILE_GROUP(1, true, true, false);
-            if (!lazy) break;
-            LECLIP_TILE_GROUP(0, true, true, false);
-        }
-        while (lazy && t < ntiles) {              // at most three more groups, either parity
-            const int left = ntiles - 1 - t;      // tiles after t
-            if (t & 1) {
-                if (left >= 2) LECLIP_TILE_GROUP(1, true, true, false);
-                else if (left == 1) LECLIP_TILE_GROUP(1, true, false, false);
-                else LECLIP_TILE_GROUP(1, false, false, true);
-            } else {
-                if (left >= 2) LECLIP_TILE_GROUP(0, true, true, false);
-                else if (left == 1) LECLIP_TILE_GROUP(0, true, false, false);
-                else LECLIP_TILE_GROUP(0, false, false, true);
-            }
-        }
-#undef LECLIP_TILE_GROUP
-        if (lazy) {
-            // PV of the last tile (its V^T fragments were requested by its own group - or by the prologue)
-            if ((ntiles - 1) & 1) tile_pv<T, 1>(st); else tile_pv<T, 0>(st);
-        } else {
-            // Rare: some query's scores in tile t are far above its reference maximum.  O and the row sum hold tiles 0 .. t - 1 (group t has
-            // issued PV of tile t - 1 before its check); the rest of the block runs the exact recurrence, one tile at a time.
-            for (; t < ntiles; ++t) {
-                tile_exact<T, false>(st, kA, qf, t, t == ntiles - 1, lim_last);
-                tile_read_v<T>(st, vB, t);
-                tile_pv<T, 0>(st);
-            }
-        }
-        // the next block's Q (requested a whole block ago) moves in before this block's stores
-        if (has_next) {
-#pragma unroll
-            for (int s = 0; s < 4; ++s) qf[s] = qn[s];
-            prescale_q(qf);
-        }
-        const float inv = 1.0f / lane32_sum(st.l_part);
-        attn_store_block<T>(st.o, inv, obase + (int64_t)qi * a.ld_out, fh, qi < a.T);
-    }
-}
-#endif   // LECLIP_ATTN_TILE
-
 // ---------------------------------------------------------------- fp32 validation kernel
 // One workgroup per (batch, head), K and V in LDS as fp32 (rows padded to 65 floats), one query row per wave at
 // a time: lanes own keys for the scores, then own output dimensions for P.V.  T <= 304 (LDS budget).
@@ -1126,17 +841,6 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
         if (a.causal) {
             leclip_set_max_lds(attn_stream_kernel<T, true>, STREAM_TMAX * 256, attr_set_c);
             hipLaunchKernelGGL((attn_stream_kernel<T, true>), dim3(grid), dim3(512), TP * 256, s, a, TP);
-#ifdef LECLIP_ATTN_TILE
-        } else if (true) {
-            static bool attr_set_t[LECLIP_MAX_DEVICES] = {};
-            const int TP32 = (a.T + 31) & ~31;
-#ifndef LECLIP_ATTN_TILE_NW
-#define LECLIP_ATTN_TILE_NW 8
-#endif
-            leclip_set_max_lds((attn_tile_kernel<T, LECLIP_ATTN_TILE_NW>), STREAM_TMAX * 256, attr_set_t);
-            hipLaunchKernelGGL((attn_tile_kernel<T, LECLIP_ATTN_TILE_NW>), dim3(grid), dim3(LECLIP_ATTN_TILE_NW * 64), TP32 * 256, s, a, TP32);
-            return leclip_check_launch("attn_tile_kernel");
-#endif
         } else {
             leclip_set_max_lds(attn_stream_kernel<T, false>, STREAM_TMAX * 256, attr_set);
             hipLaunchKernelGGL((attn_stream_kernel<T, false>), dim3(grid), dim3(512), TP * 256, s, a, TP);

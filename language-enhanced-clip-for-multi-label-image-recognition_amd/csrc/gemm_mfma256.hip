@@ -125,9 +125,6 @@ struct PP {
     char* smem;
     acc4 acc[2][4][4];
     v8 af[4], bfr[4];
-#ifdef LECLIP_KLOOP_FR
-    v8 af2[4], bf2[4];   // free-running schedule: second fragment set (reads run one 16-MFMA block ahead of their use)
-#endif
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
     int dbg;             // diagnostic build: LECLIP_GEMM_DEBUG bits 8 (no steady-state LDS-DMA), 16 (no MFMA), 32 (no fragment reads)
     unsigned* fine;      // diagnostic build: LDS slot array of this wave for the per-phase timeline of ONE K-tile (null = off)
@@ -189,116 +186,6 @@ struct PP {
         PIN();
     }
 
-#ifdef LECLIP_KLOOP_FR
-    // ---- Free-running schedule (the product schedule from round 3 on; the ping-pong form below is kept for A/B builds) ----
-    // Every wave is software-pipelined by itself: the fragment reads of a 16-MFMA block are issued, one or two per MFMA,
-    // between the MFMAs of the block BEFORE it (second fragment set), and so are the LDS-DMA pieces.  No wave waits for its
-    // SIMD partner; the matrix pipe of a SIMD takes MFMAs from whichever of its two waves has one ready.  One s_barrier per
-    // HALF K-tile (32 MFMAs per wave) instead of two per 16:
-    //     half n = (K-tile t, k-half kh), ring slot pair (stage t & 1, kh)       blocks: P0 = rows r0, P1 = rows r1
-    //     P0(n) [reads A(n, r1)]  lgkmcnt(0)  vmcnt -> half n+1 landed (this wave's pieces)   B_n
-    //     P1(n) [LDS-DMA of half n+4 into the slots of half n; reads A(n+1, r0), B(n+1)]  lgkmcnt(0)
-    // B_n certifies (WAR) that every wave has retired its reads of half n's slots - they are refilled right behind it, three
-    // barrier intervals before half n+4 is read - and (RAW) that every wave's pieces of half n+1 have landed before any
-    // wave reads them.  Same slots, same LDS-DMA pattern, same MFMA instruction and ascending-K order per accumulator as
-    // the ping-pong schedule: the results are the same bits.
-    template <int SEL, class Ops>
-    __device__ __forceinline__ void mma16(int rh, Ops&& op) {
-        v8 (&a)[4] = (SEL & 1) ? af2 : af;
-        v8 (&b)[4] = (SEL & 2) ? bf2 : bfr;
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-#ifndef LECLIP_FR_MFMA_FIRST
-            op(m);
-            PIN();
-#endif
-            const int i = m >> 2, j = m & 3;
-            if (!PPDBG(16)) acc[rh][i][j] = SWAP ? mfma16(b[j], a[i], acc[rh][i][j]) : mfma16(a[i], b[j], acc[rh][i][j]);
-            PIN();
-#ifdef LECLIP_FR_MFMA_FIRST
-            op(m);
-            PIN();
-#endif
-        }
-    }
-    __device__ __forceinline__ void read_a1(int stage, int kh, int rh, int i, v8 (&dst)[4]) {
-        const char* p = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES + a_rd + rh * (64 * 64);
-        if (!PPDBG(32)) dst[i] = *(const v8*)(p + i * 1024);
-    }
-    __device__ __forceinline__ void read_b1(int stage, int kh, int j, v8 (&dst)[4]) {
-        const char* p = smem + stage * STAGE_BYTES + (2 * kh + 1) * SLOT_BYTES + b_rd;
-        if (!PPDBG(32)) dst[j] = *(const v8*)(p + j * 1024);
-    }
-    __device__ __forceinline__ void dma1(bool is_b, int stage, int kh, int k_elem, int u) {
-        char* slot = smem + stage * STAGE_BYTES + (2 * kh + (is_b ? 1 : 0)) * SLOT_BYTES;
-        if (PPDBG(8)) return;
-        __builtin_amdgcn_global_load_lds((const void*)((is_b ? w_src[u] : a_src[u]) + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
-    }
-    // tile top (after the barrier that follows the wait for half 0): fragments of P0(0) into the first set
-    __device__ __forceinline__ void fr_first_reads() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) read_a1(0, 0, 0, i, af);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) read_b1(0, 0, j, bfr);
-        LGKM0();
-    }
-    // One K-tile = halves (t, 0) and (t, 1).  V = 0: halves n+4 of this tile exist; 1 = second to last K-tile; 2 = last.
-    // X, nx, next_src: as for the ping-pong form below (stores of the previous epilogue younger than the prologue pieces;
-    // K-loop pipelined across the tile boundary: the next tile's halves 0 and 1 are staged behind B_{N-4} and B_{N-3}, its half
-    // 2 by the kernel once the epilogue operands are in (as in the ping-pong form), its half 3 - whose slots the epilogue
-    // stages through - at the next tile's top).
-    template <int V, int X = 0, class F>
-    __device__ __forceinline__ void ktile_fr(int t, bool nx, F&& next_src) {
-        const int s = t & 1;
-        const int k2 = (t + 2) * TK;
-        // ---- half (t, 0).  P0: fragments af / bfr; reads A(k0, r1) -> af2
-        mma16<0>(0, [&](int m) { if (m < 4) read_a1(s, 0, 1, m, af2); });
-        LGKM0();
-        if (V <= 1 || nx) {
-            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        PIN();
-        __builtin_amdgcn_s_barrier();
-        PIN();
-        if (V == 1 && nx) next_src();
-        const bool d0 = V == 0 || (V == 1 && nx);             // something is staged behind this barrier
-        const int kd0 = V == 0 ? k2 : 0;                      // this tile's half (t+2, 0) | next tile's half 0
-        // P1: fragments af2 / bfr; reads A(k1, r0) -> af, B(k1) -> bf2; LDS-DMA into the k0 slots
-        mma16<1>(1, [&](int m) {
-            if (m < 4) read_a1(s, 1, 0, m, af);
-            else if (m < 8) read_b1(s, 1, m - 4, bf2);
-            else if (d0 && !(m & 1)) dma1(m < 12, s, 0, kd0, (m >> 1) & 1);   // m = 8, 10: B pieces; 12, 14: A pieces
-        });
-        LGKM0();
-        // ---- half (t, 1).  P0: fragments af / bf2; reads A(k1, r1) -> af2
-        mma16<2>(0, [&](int m) { if (m < 4) read_a1(s, 1, 1, m, af2); });
-        LGKM0();
-        if (V == 0 || (V == 1 && nx)) {
-            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + X) : "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else if (V == 1) {
-            if (X > 0 && t == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 + X) : "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        }
-        PIN();
-        __builtin_amdgcn_s_barrier();
-        PIN();
-        const bool d1 = V == 0 || (V == 1 && nx);
-        const int kd1 = V == 0 ? k2 + 32 : 32;                // this tile's half (t+2, 1) | next tile's half 1
-        // P1: fragments af2 / bf2; reads of the next K-tile's P0 (stage 1-s) -> af, bfr; LDS-DMA into the k1 slots
-        mma16<3>(1, [&](int m) {
-            if (V <= 1) {
-                if (m < 4) read_a1(1 - s, 0, 0, m, af);
-                else if (m < 8) read_b1(1 - s, 0, m - 4, bfr);
-            }
-            if (m >= 8 && d1 && !(m & 1)) dma1(m < 12, s, 1, kd1, (m >> 1) & 1);
-        });
-        LGKM0();
-    }
-#endif
 
     // One K-tile.  V = 0 steady state (tiles t+1 and t+2 exist), 1 = second to last (only t+1 exists), 2 = last.
     // X: vector-memory operations that are YOUNGER than the next tile's prologue DMA but are not K-loop DMA - the
@@ -471,14 +358,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         PIN();
         __builtin_amdgcn_s_barrier();
         PIN();
-#ifdef LECLIP_KLOOP_FR
-        // half 3 (K-tile 1's k1 slots): its slots were the previous tile's epilogue staging, free behind this barrier
-        p.stage_b(1, 1, TK + 32);
-        p.stage_a(1, 1, TK + 32);
-        p.fr_first_reads();
-#else
         if (wm == 1) __builtin_amdgcn_s_barrier();   // stagger: the second M-half runs one barrier behind
-#endif
         PIN();
 
         STAMP(0);
@@ -506,17 +386,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             p.fine_i = 0;
         }
 #else
-#ifdef LECLIP_KLOOP_FR
-        for (; t + 2 < nk; ++t) p.template ktile_fr<0, EPI_STORES>(t, false, next_src);
-#else
         for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
 #endif
-#endif
-#ifdef LECLIP_KLOOP_FR
-        p.template ktile_fr<1, EPI_STORES>(t, nx, next_src);
-#else
         p.template ktile<1, EPI_STORES>(t, nx, next_src);
-#endif
 
         // T16 flavour: the per-column constants (bias | fused-LayerNorm column sums: 2 x 256 floats per tile, one per
         // thread) and the lane's two (mean, rstd) pairs are requested BEFORE the last K-tile - 1 + 4 registers, older than
@@ -543,11 +415,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             p.fine_i = 0;
         }
 #endif
-#ifdef LECLIP_KLOOP_FR
-        p.template ktile_fr<2>(t + 1, nx, next_src);
-#else
         p.template ktile<2>(t + 1, nx, next_src);
-#endif
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
         p.fine = nullptr;
 #endif
@@ -622,9 +490,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             cst[tid] = cpre;
         }
         PIN();
-#ifndef LECLIP_KLOOP_FR
         if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
-#endif
         PIN();
         __syncthreads();                             // every wave is done reading the K-loop buffers (and has published its constant)
         if constexpr (T16) {

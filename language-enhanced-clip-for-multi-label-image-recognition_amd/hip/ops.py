@@ -526,18 +526,22 @@ def local_pool(sim: torch.Tensor, batch: int, tokens: int, first: int, n_cls: in
 def topk_mix(img: torch.Tensor, feats: torch.Tensor, k: int = 10) -> torch.Tensor:
     """(img + mean of the k rows of ``feats`` most similar to img) / 2 per row of ``img`` - the caption-feature mixing of
     Caption_distill_double.py:444-448.  img [B, E] and feats [N, E] fp32, both already normalised; the similarity panel runs on the
-    exact-fp32 MFMA GEMM (feats zero-padded to the GEMM's row granularity once by the caller's cache: ``feats_padded``)."""
+    exact-fp32 MFMA GEMM (its N granularity is 64 rows: a table that is a view of a zero-padded one - as DenseCLIP.set_caption_text_feats
+    keeps it - is used in place, anything else is padded per call)."""
     _dev(img, "img")
     _dev(feats, "feats")
     if img.dtype != torch.float32 or feats.dtype != torch.float32 or not img.is_contiguous() or not feats.is_contiguous() or img.shape[1] != feats.shape[1]:
         raise TypeError("topk_mix: img [B, E] and feats [N, E] must be contiguous float32")
     n, e = feats.shape
     npad = (n + 63) // 64 * 64
-    if npad != n:      # the GEMM's N granularity; the padded columns are never selected (the kernel scans [0, n))
+    base = feats._base if feats._base is not None else None
+    if npad == n:
+        w = feats
+    elif base is not None and base.dim() == 2 and base.shape == (npad, e) and base.data_ptr() == feats.data_ptr() and base.is_contiguous():
+        w = base       # the caller's table is a view of one already padded to the GEMM's N granularity (DenseCLIP.set_caption_text_feats)
+    else:              # ad-hoc call: pad here; the padded columns are never selected (the kernel scans [0, n))
         w = torch.zeros((npad, e), dtype=torch.float32, device=feats.device)
         w[:n] = feats
-    else:
-        w = feats
     sim = gemm(img, w, out_dtype=torch.float32)                   # [B, npad]
     out = torch.empty_like(img)
     _capi.check(_capi.load().leclip_topk_mix_fwd(_ptr(sim), _ptr(feats), _ptr(img), _ptr(out), img.shape[0], n, e, int(k), npad, _stream()), "topk_mix")

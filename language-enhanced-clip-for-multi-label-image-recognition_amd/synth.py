@@ -192,7 +192,9 @@ def _block_specs(prefix: str, d: int, layers: int, dist: str, text: bool) -> Dic
 
 
 def state_dict_specs(arch: ClipArch, dist: str = "cond", towers: str = "both") -> Dict[str, tuple]:
-    assert dist in ("cond", "default") and towers in ("both", "visual", "text")
+    assert dist in ("cond", "default", "outlier") and towers in ("both", "visual", "text")
+    if dist == "outlier":      # the "cond" draws, then the deterministic channel edits of _outlier_edit (make_state_dict)
+        dist = "cond"
     sp: Dict[str, tuple] = {}
     w, p = arch.vision_width, arch.vision_patch_size
     if towers in ("both", "visual"):
@@ -233,12 +235,54 @@ def make_tensor(seed: int, name: str, spec: tuple) -> np.ndarray:
     return round_fp16(a)
 
 
+def outlier_channels(d: int):
+    """The three residual-stream channels of a tower of width ``d`` that dist="outlier" turns into massive-activation channels."""
+    return (d // 7, d // 3 + 1, (5 * d) // 8 + 2)
+
+
+def _outlier_edit(name: str, a: np.ndarray, arch: ClipArch) -> np.ndarray:
+    """dist="outlier": the statistics of a RELEASED checkpoint that the benign synthetic sets lack (missing 3) - a handful of
+    residual-stream channels 50 - 150 times the typical magnitude, fed by ln_pre / positional-embedding offsets and by c_proj biases
+    that keep pushing them block after block, LayerNorm gains that damp exactly those channels (as trained models do), and a
+    non-zero mean over a row's ordinary channels.  Constants only (no extra random draws), every value fp16-representable.  This is the
+    input the folded LayerNorm (hip/engine.py _fold_ln: rstd * (x . W'^T - mean * colsum)) is stressed by: the row variance is
+    dominated by three channels, rstd of the ordinary channels drops to ~0.3, and the outliers sit where 16-bit rounding is coarse."""
+    vis = name.startswith("visual.")
+    d = arch.vision_width if vis else arch.transformer_width
+    ch = outlier_channels(d)
+    big = (72.0, -54.0, 90.0)
+    push = (9.0, -6.0, 12.0)
+    a = a.copy()
+    if name in ("visual.ln_pre.bias",):
+        a += 0.375                                   # ordinary channels: row mean well away from 0
+        for c, v in zip(ch, big):
+            a[c] = v
+    elif name in ("visual.ln_pre.weight",):
+        for c in ch:
+            a[c] = 2.0
+    elif name == "positional_embedding":             # text tower: the same three-channel offset on every position
+        for c, v in zip(ch, big):
+            a[:, c] = v * 0.5
+        a += 0.125
+    elif name.endswith(("ln_1.weight", "ln_2.weight")) or name in ("visual.ln_post.weight", "ln_final.weight"):
+        if name.endswith(("ln_1.weight", "ln_2.weight")):
+            a *= 2.5                                 # ordinary channels: gains that make up for the small rstd (the outliers own the variance)
+        for c in ch:
+            a[c] = 0.03125                           # damped, as trained LayerNorms damp their massive channels
+    elif name.endswith("mlp.c_proj.bias"):
+        for c, v in zip(ch, push):
+            a[c] = v                                 # +- 50 .. 100 more over twelve blocks
+    return round_fp16(a)
+
+
 def make_state_dict(arch: ClipArch, seed: int = 0, dist: str = "cond", towers: str = "both",
                     as_torch: bool = True):
     """Synthetic OpenAI-CLIP-shaped state-dict (fp32 tensors holding fp16-representable values)."""
     sd = {}
     for name, spec in state_dict_specs(arch, dist, towers).items():
         a = make_tensor(seed, name, spec)
+        if dist == "outlier":
+            a = _outlier_edit(name, a, arch)
         if as_torch:
             import torch
             sd[name] = torch.from_numpy(np.ascontiguousarray(a)).reshape(a.shape)

@@ -289,6 +289,12 @@ class DenseCLIP(CustomCLIP):
             feats = feats.detach().to(device=dev, dtype=torch.float32).contiguous()
             if feats.dim() != 2 or feats.shape[0] < 10:
                 raise ValueError("caption_text_feats must be [N >= 10, E]")
+            n = feats.shape[0]
+            npad = (n + 63) // 64 * 64               # the similarity GEMM's row granularity: padded ONCE here, not per test batch
+            if npad != n:
+                padded = torch.zeros((npad, feats.shape[1]), dtype=torch.float32, device=dev)
+                padded[:n] = feats
+                feats = padded[:n]                   # a view of the padded table: ops.topk_mix finds the pad rows behind it
         self.caption_text_feats = feats
 
     @torch.no_grad()
@@ -670,11 +676,9 @@ class Caption_distill_double:
                 raise TypeError("DenseCLIP is tuned on tokenised captions [B, 77] (texts as images); image batches tune CustomCLIP")
             output, output_local, _, _, output_m, output_local_m = model(None, inp.long())
         elif inp.dtype in (torch.int64, torch.int32):
-            res = model(None, inp.long())
-            output, output_m = res[0], res[3]
+            output = model(None, inp.long())[0]      # CustomCLIP returns (logits, None, None, None) (:352): no momentum scores, no KL term
         else:
-            res = model(inp, None)
-            output, output_m = res[0], res[3]
+            output = model(inp, None)[0]
         lf = self.cfg.TRAIN.LOSSFUNC
         summary = {}
         if lf == "double_ranking":
@@ -689,8 +693,10 @@ class Caption_distill_double:
                 ema_loss = kl(logp(output, dim=-1), torch.softmax(output_m, dim=-1))
                 if output_local is not None and output_local_m is not None:
                     ema_loss = ema_loss + kl(logp(output_local, dim=-1), torch.softmax(output_local_m, dim=-1)) * 10000
-                summary = {"r_loss": loss.item(), "ema_loss": ema_loss.item()}
+                r_loss = loss
                 loss = loss + ema_loss
+                vals = torch.stack([r_loss.detach(), ema_loss.detach()]).tolist()     # one host sync for the summary scalars
+                summary = {"r_loss": vals[0], "ema_loss": vals[1]}
         elif lf == "bce":
             loss = norm_logits_BCEloss(output, label.float())
             if output_local is not None:

@@ -416,6 +416,100 @@ def test_vitb16_cfg1_golden(ops, golden_dir, dt, dist):
         assert np.array_equal(lpi.argmax(1)[ok], ref.argmax(1)[ok])
 
 
+# constant label-index bands (VERDICT r3 weak 2 / task 7): two oracle logits closer than the band cannot be ordered by arithmetic with that
+# error, a disagreement outside it is a wrong result.  Derived once from the measured maximum logit error at scale 4.0 (fp16 2.5e-3 - 3.1e-3,
+# bf16 2.8e-2 - 3.3e-2 over rounds 2 - 4), doubled for the two logits involved; a uniformly worse kernel no longer widens its own band.
+LABEL_BAND = {torch.float32: 1e-4, torch.float16: 6e-3, torch.bfloat16: 6e-2}
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_vitb16_outlier_golden(ops, golden_dir, dt):
+    """ViT-B/16, B=8, weights with the statistics of a released checkpoint (synth dist="outlier": three massive-activation channels per
+    residual stream, 50 - 90 sigma after ln_pre and +-140 - 240 after the last block, damped LayerNorm gains, non-zero row means)
+    against the REFERENCE's forward on the same weights (tests/golden/vitb16_outlier.npz).  Stresses exactly what the benign sets do not:
+    the folded LayerNorm's rstd * (x.W'^T - mean * colsum) on rows whose variance three channels own, and 16-bit rounding where it is
+    coarse."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.trainers import CustomCLIP
+    g = np.load(os.path.join(golden_dir, "vitb16_outlier.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    sd = synth.make_state_dict(synth.VIT_B16, seed=0, dist="outlier")
+    assert np.array_equal(sd["visual.ln_pre.bias"].numpy()[:16], g["guard.ln_pre_bias_head"])     # generator drift guard
+    m = _build(synth.VIT_B16, 0, "outlier", dt)
+    img = torch.from_numpy(synth.make_images(8, 224, seed=1234)).to(DEV)
+    lpi, _ = m(img, torch.from_numpy(t["tokens_photo"]).to(DEV))
+    lpi = lpi.cpu().numpy()
+    err = float(np.abs(lpi - g["logits_clip"]).max())
+    fi = m.encode_image(img).float().cpu().numpy()
+    cc = CustomCLIP(get_cfg_default(), coco_object_categories, m.cpu())
+    with torch.no_grad():
+        cc.prompt_learner.ctx.copy_(torch.from_numpy(synth.make_ctx(16, 512, seed=0)))
+    cc.to(DEV).eval()
+    with torch.no_grad():
+        lcc = cc(img, if_test=True)[0].float().cpu().numpy()
+    err_cc = float(np.abs(lcc - g["logits_custom_ctx16"]).max())
+    print(f"outlier weights [{dt}]: max|dlogit| CLIP (scale 14.3) {err:.3e}, CustomCLIP (scale 4) {err_cc:.3e}")
+    assert err <= _tol(dt, 1e-3, 3e-2, 2.5e-1) and err_cc <= _tol(dt, 1e-3, 8e-3, 7e-2), (err, err_cc)
+    if dt == torch.float32:
+        assert np.array_equal(np.argsort(-lpi, axis=1, kind="stable")[:, :5], g["top5_clip"])
+        assert np.array_equal(np.argsort(-lcc, axis=1, kind="stable")[:, :5], g["top5_custom_ctx16"])
+        np.testing.assert_allclose(fi, g["image_features"], atol=1e-3, rtol=1e-3)
+    else:
+        ok = _margin_ok(g["logits_custom_ctx16"], LABEL_BAND[dt] / 2)
+        assert np.array_equal(lcc.argmax(1)[ok], g["logits_custom_ctx16"].argmax(1)[ok])
+
+
+def _cfg4_fixture(golden_dir):
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg4_logits.npz"))
+    labels = np.unpackbits(g["labels"], axis=1)[:, :int(g["n_classes"])].astype(np.int64)
+    return g["logits"], labels, float(g["mAP_reference"])
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16, torch.float32])
+def test_cfg4_logits_against_the_reference_at_size(ops, golden_dir, dt):
+    """BASELINE configs[3] at the survey's N = 2 048, pinned to the REFERENCE itself: tests/golden/vitb16_cfg4_logits.npz
+    holds the logits of the reference's model.py on the eight ranks' images (oracle/make_golden.py cfg4_goldens), the labels drawn from
+    them and the reference mAP().  Per dtype: max |logit difference|, label-index agreement outside the CONSTANT band, |mAP - reference|.
+    This is what settles the bf16 clause: at N = 2 048 the sampling noise of 192-image samples is gone."""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.evaluation import mAP
+    from leclip_amd.trainers import CustomCLIP
+    ref, labels, m_ref = _cfg4_fixture(golden_dir)
+    assert abs(mAP(labels, ref) - m_ref) < 1e-9          # our mAP() on the fixture's rows == the reference's mAP() value
+    m = _build(synth.VIT_B16, 0, "cond", dt).cpu()
+    cc = CustomCLIP(get_cfg_default(), coco_object_categories, m)
+    with torch.no_grad():
+        cc.prompt_learner.ctx.copy_(torch.from_numpy(synth.make_ctx(16, 512, seed=0)))
+    cc.to(DEV).eval()
+    n = 2048 if dt != torch.float32 else 512            # (the exact-fp32 validation path is 20 x slower: a quarter of the set)
+    hip = []
+    with torch.no_grad():
+        for r in range(n // 256):
+            img = torch.from_numpy(synth.make_images(256, 224, seed=1234, start=256 * r)).to(DEV)
+            hip.append(cc(img, if_test=True)[0].float().cpu().numpy())
+    hip = np.concatenate(hip)
+    ref = ref[:n]
+    err = float(np.abs(hip - ref).max())
+    r1, h1 = ref.argmax(1), hip.argmax(1)
+    dis = np.nonzero(r1 != h1)[0]
+    worst = max([float(ref[i, r1[i]] - ref[i, h1[i]]) for i in dis], default=0.0)     # the oracle's margin to the label the HIP path picked
+    line = f"cfg4 [{dt}] N={n}: max|dlogit| {err:.3e}, top-1 agreement {1 - len(dis) / n:.4f} ({len(dis)} differ, worst reference margin {worst:.2e})"
+    if n == 2048:
+        m_hip = mAP(labels, hip)
+        line += f", mAP reference {m_ref:.3f} hip {m_hip:.3f} (delta {m_hip - m_ref:+.3f})"
+    print(line)
+    assert err <= _tol(dt, 1e-3, 4e-3, 4e-2), err
+    assert worst <= LABEL_BAND[dt], (worst, LABEL_BAND[dt])
+    if dt == torch.float32:
+        assert len(dis) == 0
+    elif dt == torch.float16:
+        assert abs(m_hip - m_ref) <= 0.2                 # the north star's clause, at size, against the reference
+    else:
+        assert abs(m_hip - m_ref) <= 0.35                # bf16: measured (round 4) - see DESIGN section 3 for the decision this number backs
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_custom_clip_golden(ops, golden_dir, dt):
     """CustomCLIP (learnable 16-token context, x4.0 cosine logits), image branch and caption-as-image branch."""
@@ -903,8 +997,18 @@ def test_fused_layernorm_on_large_mean_rows(ops, dt):
         ref = ((xd - mu) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()) @ w.double().t() + b.double()
         out = ops.gemm_ln(x.to(DEV), wf, cb, ln_stats=st, ln_colsum=cs, out_dtype=torch.float32)
         err = float((out.double().cpu() - ref).abs().max())
-        # error budget: W' = gamma * W rounded to 16 bits (relative 2^-9 / 2^-12) times |x - mean| ~ outliers of 150 std
-        assert err <= (0.35 if dt == torch.bfloat16 else 0.05) * float(ref.abs().max()), (err, float(ref.abs().max()))
+        # Yardstick: the UNFUSED path on the same rows - the LayerNorm kernel writes h = LN(x) rounded to 16 bits, a plain GEMM multiplies it
+        # with W rounded to 16 bits.  The folded form rounds W' = gamma * W instead of h and W; both carry one 16-bit rounding per
+        # product term, dominated by the 150-sigma channels (|x - mean| * rstd ~ 20 at eps 2^-11 / 2^-8).
+        h = ops.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+        plain = ops.gemm(h, w.to(dt).to(DEV), b.to(DEV), out_dtype=torch.float32)
+        err_plain = float((plain.double().cpu() - ref).abs().max())
+        scale = float(ref.abs().max())
+        print(f"fused-LN [{dt}, {m}x{n}x{k}]: folded err {err:.3e}, unfused (layernorm -> gemm) err {err_plain:.3e}, max|ref| {scale:.2f}")
+        # bounds: 2 x the measured error of each path (round 4: fp16 folded 1.1e-3 / unfused 2.2e-3 of max|ref| ... see the printed line),
+        # and the folded form may not be worse than twice the unfused one
+        assert err <= (2.5e-2 if dt == torch.bfloat16 else 3.5e-3) * scale, (err, scale)
+        assert err <= 2.0 * err_plain + 1e-4 * scale, (err, err_plain)
 
 
 def test_rccl_gather_path_single_rank(tmp_path):

@@ -83,6 +83,52 @@ def test_vitb16_cfg1(golden_dir, dist):
     np.testing.assert_allclose(lcap.numpy(), g[dist + ".logits_custom_captions"], atol=2e-5, rtol=0)
 
 
+def test_vitb16_outlier_weights(golden_dir):
+    """The oracle on the third weight set (synth dist="outlier": massive-activation channels, damped LayerNorm gains) against the
+    reference's forward on the same weights - the fixture the GPU suite holds all three dtypes to."""
+    g = np.load(os.path.join(golden_dir, "vitb16_outlier.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    sd = _sd(synth.VIT_B16, 0, "outlier")
+    assert np.array_equal(sd["visual.ln_pre.bias"].numpy()[:16], g["guard.ln_pre_bias_head"])
+    assert np.array_equal(np.array(synth.outlier_channels(768)), g["outlier_channels"])
+    assert np.abs(g["residual_outlier_mean"]).min() > 10 * float(g["residual_ordinary_std"])     # the fixture really has massive channels
+    img = torch.from_numpy(synth.make_images(8, 224, seed=1234))
+    fi = co.encode_image(img, sd)
+    np.testing.assert_allclose(fi.numpy(), g["image_features"], atol=2e-4, rtol=2e-4)
+    tctx = torch.from_numpy(t["tokens_ctx16"])
+    ctx = torch.from_numpy(synth.make_ctx(16, 512, seed=0))
+    prefix, suffix = co.prompt_buffers(tctx, sd, 16)
+    txt = co.text_encoder(co.prompt_learner_forward(ctx, prefix, suffix), tctx, sd)
+    np.testing.assert_allclose(txt.numpy(), g["text_features_ctx16"], atol=2e-4, rtol=2e-4)
+    lc = co.cosine_logits(fi, txt, 4.0)
+    np.testing.assert_allclose(lc.numpy(), g["logits_custom_ctx16"], atol=5e-5, rtol=0)
+    assert np.array_equal(torch.topk(lc, 5, dim=1).indices.numpy(), g["top5_custom_ctx16"])
+
+
+def test_cfg4_reference_logits_fixture(golden_dir):
+    """tests/golden/vitb16_cfg4_logits.npz (the reference's logits on the 2 048 images of BASELINE configs[3]): the oracle reproduces a
+    slice of it (four images of three different ranks' shards), the packed labels are synth.make_labels_from_logits of those logits, and
+    our mAP() on them equals the value the reference's mAP() returned when the fixture was made."""
+    from leclip_amd.evaluation import mAP
+    g = np.load(os.path.join(golden_dir, "vitb16_cfg4_logits.npz"))
+    t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
+    ref = g["logits"]
+    labels = np.unpackbits(g["labels"], axis=1)[:, :int(g["n_classes"])].astype(np.int64)
+    assert ref.shape == (2048, 80) and labels.shape == (2048, 80)
+    assert np.array_equal(labels, synth.make_labels_from_logits(ref, seed=7, pos_frac=0.1, noise=0.5))
+    assert mAP(labels, ref) == pytest.approx(float(g["mAP_reference"]), abs=1e-9)
+    assert np.array_equal(ref.argmax(1).astype(np.int16), g["top1"])
+    sd = _sd(synth.VIT_B16, 0, "cond")
+    tctx = torch.from_numpy(t["tokens_ctx16"])
+    ctx = torch.from_numpy(synth.make_ctx(16, 512, seed=0))
+    prefix, suffix = co.prompt_buffers(tctx, sd, 16)
+    txt = co.text_encoder(co.prompt_learner_forward(ctx, prefix, suffix), tctx, sd)
+    for start in (0, 777, 2044):
+        img = torch.from_numpy(synth.make_images(4, 224, seed=1234, start=start))
+        lc = co.cosine_logits(co.encode_image(img, sd), txt, 4.0)
+        np.testing.assert_allclose(lc.numpy(), ref[start:start + 4], atol=3e-5, rtol=0)
+
+
 def test_prompt_identity_kat(golden_dir):
     """ctx := token_embedding('x') repeated => prompts == token_embedding(tokens)."""
     t = np.load(os.path.join(golden_dir, "tokens_coco80.npz"))
