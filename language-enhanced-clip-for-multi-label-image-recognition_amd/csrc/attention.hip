@@ -24,6 +24,7 @@ struct AttnArgs {
 #ifdef LECLIP_DIAG
     WgLog wglog;
 #endif
+    int reverse;        // attn_heads_kernel: walk the (batch, head) pairs from the last to the first
     int q_rows;         // 0: every query row; n > 0: only the first n query rows of every (batch, head) are computed and stored
                         // (leclip_attention_prefix_fwd: the last block of the image tower needs the class token's row only)
 };
@@ -326,7 +327,12 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     const int d_model = a.heads * 64;
     const int last = total_heads - 1;
 
+    // Walk order: the LAST (batch, head) pairs first.  The packed qkv rows were written by the GEMM in front of this kernel in ascending row
+    // order, so the tail of the tensor is what the memory-side cache (256 MiB; the tensor is 232 MB at B = 256) still holds - an
+    // ascending walk asks for the oldest lines first and evicts the youngest as it goes (round 4: profiles/r04_attention_order.txt).
+    auto eff = [&](int hd) { return a.reverse ? total_heads - 1 - hd : hd; };
     auto head_base = [&](int hd) {
+        hd = eff(hd);
         const int b = hd / a.heads, h = hd - b * a.heads;
         return (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
     };
@@ -390,7 +396,8 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
             __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0), as the compiler's own instruction (its scoreboard then knows the Q fragments are in: no second wait in front of the first MFMA): the Q image may be refilled
             issue(nb, cur ^ 1);
             issue_q(nb);
-            const int b = hd / a.heads, h = hd - b * a.heads;
+            const int he = eff(hd);
+            const int b = he / a.heads, h = he - b * a.heads;
             T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
             attn_qblock<T, NKT, true>(a, smem + cur * 2 * BUF, smem + cur * 2 * BUF + BUF, q, obase, wave, lane);
             // Everything older than this head's 4 output stores has completed: the next head's K/V share and Q image
@@ -878,6 +885,11 @@ extern "C" int leclip_attention_prefix_fwd(const void* qkv, void* out, int64_t B
     a.qkv = qkv; a.out = out; a.T = T; a.heads = heads; a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
     a.q_rows = q_rows == T ? 0 : q_rows;
+#ifdef LECLIP_ATTN_FORWARD_ORDER      // A/B builds: the round-3 walk order
+    a.reverse = 0;
+#else
+    a.reverse = 1;
+#endif
 #ifdef LECLIP_DIAG
     a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
 #endif

@@ -56,6 +56,8 @@ struct Gemm256Args {
     int64_t lda, ldw;
     EpiParams epi;
     int tiles_n, tiles_total;
+    int im_R, im_G;   // IM2COL kernels: A is an NCHW image batch [B][3][R][R] of 16-bit pixels, row m = patch (b, gy, gx) of a G x G grid of 16 x 16
+                      // patches, k = c * 256 + ky * 16 + kx (Conv2d weight order, clip/model.py:247); 0 = A is a plain [M][lda] matrix
     int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
 #ifdef LECLIP_DIAG
     WgLog wglog;
@@ -113,7 +115,11 @@ __device__ __forceinline__ char* uniform_ptr(char* p) {
 // SWAP: feed the MFMA with (W fragment, A fragment) instead of (A, W): the accumulator block (i, j) of lane l then holds
 // C[16i + (l & 15)][16j + 4(l >> 4) + r], r = 0..3 - one output row, four consecutive columns - instead of four rows of one
 // column (the fragments themselves are loaded identically: both operands are K-contiguous rows with the same lane map).
-template <typename T, bool SWAP>
+// IM2COL: the A operand is gathered straight from the image (im2col-free patch embedding): a 32-deep K-half slot holds two pixel rows
+// (ky, ky + 1) of one channel for each of the 256 patches - 2 x 32 contiguous bytes per patch - so an LDS-DMA piece is the same 16 rows x
+// 64 B as for a matrix operand, only the per-lane SOURCE address differs (patch origin + which of the two pixel rows / which half of it,
+// folded into a_src once per tile) and the K offset of a slot is (channel, pixel row) -> c * R * R + ky * R instead of k itself (scalar).
+template <typename T, bool SWAP, bool IM2COL = false>
 struct PP {
     typedef typename VecOf<T>::v8 v8;
     // per-lane constants
@@ -123,6 +129,7 @@ struct PP {
     int a_rd;            // LDS byte offset (inside an A slot) of this lane's fragment row/chunk, row-half 0, tile 0
     int b_rd;            // same for a B slot
     char* smem;
+    int im_R, im_RR;     // IM2COL: image row / channel strides in elements
     acc4 acc[2][4][4];
     v8 af[4], bfr[4];
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
@@ -142,6 +149,7 @@ struct PP {
     __device__ __forceinline__ void stage_a(int stage, int kh, int k_elem) {
         char* slot = smem + stage * STAGE_BYTES + (2 * kh) * SLOT_BYTES;
         if (PPDBG(8)) return;
+        if constexpr (IM2COL) k_elem = (k_elem >> 8) * im_RR + ((k_elem & 255) >> 4) * im_R;   // (channel, first pixel row of the slot)
 #pragma unroll
         for (int u = 0; u < 2; ++u)
             __builtin_amdgcn_global_load_lds((const void*)(a_src[u] + k_elem), LDS_PTR(slot + dma_off[u]), 16, 0, 0);
@@ -250,17 +258,20 @@ struct PP {
 // 3 generic (epilogue operands loaded inside the pass loop).
 // CFG >= 0 selects the specialised epilogue (epi_fast_chunk): bit 0 = QuickGELU, bit 1 = emit LayerNorm partial row
 // sums; the host only picks it when output / residual are of type T and there is no row remap.  CFG < 0: generic code.
-template <typename T, int PF, int CFG>
+template <typename T, int PF, int CFG, bool IM2COL = false>
 __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
 
-    // T16: the epilogue flavour that stages the FINISHED 16-bit output through LDS (kernels without a residual)
-    constexpr bool T16 = CFG >= 0 && PF != 1;
-    PP<T, T16> p;
+    // T16: the specialised epilogue - the branch value (bias / fused LayerNorm / QuickGELU applied, rounded to T) is staged through LDS in
+    // 16 bits; the residual flavours add the 16-bit residual after the read-back (round 4: they staged fp32 before)
+    constexpr bool T16 = CFG >= 0;
+    PP<T, T16, IM2COL> p;
     p.smem = smem;
+    p.im_R = g.im_R;
+    p.im_RR = g.im_R * g.im_R;
 #if defined(LECLIP_DIAG) && defined(LECLIP_GEMM_STAMPS)
     p.fine = nullptr;
     p.fine_i = 0;
@@ -299,7 +310,17 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             const int r = (wave + 8 * u) * 16 + dma_r;
             int64_t ar = m0 + r;
             ar = ar < g.M ? ar : g.M - 1;
-            p.a_src[u] = (const T*)g.A + ar * g.lda + dma_c;
+            if constexpr (IM2COL) {
+                // patch row -> (image, grid row, grid column); the lane's logical 16-byte chunk of the slot's 64-byte row: chunk >> 1 =
+                // which of the slot's two pixel rows, chunk & 1 = which half of the patch's 16 pixels
+                const int pp = g.im_G * g.im_G;
+                const int64_t b = ar / pp;
+                const int pi = (int)(ar - b * pp), gy = pi / g.im_G, gx = pi - gy * g.im_G;
+                const int cl = dma_c >> 3;
+                p.a_src[u] = (const T*)g.A + ((b * 3) * g.im_R + gy * 16 + (cl >> 1)) * (int64_t)g.im_R + gx * 16 + (cl & 1) * 8;
+            } else {
+                p.a_src[u] = (const T*)g.A + ar * g.lda + dma_c;
+            }
             p.w_src[u] = (const T*)g.W + (int64_t)(n0 + r) * g.ldw + dma_c;
         }
     };
@@ -462,14 +483,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         // residual: 16-byte chunk qu of this lane.  Fetched in two batches of 8 (= 32 VGPRs each): the first here, the
         // second from inside the epilogue once the first two accumulator strips are parked and their registers are free,
         // but still ahead of the first output store (vmcnt retires in order: a load behind stores waits for them).
-        auto load_res = [&](int qu, int crow, int n) {
-            int64_t m = em0 + wm * 128 + (qu >> 1) * 16 + (qu & 1) * 8 + crow;
-            m = m < g.M ? m : g.M - 1;
-            return *(const i32x4*)((const char*)e.res + (m * e.ldr + n) * 2);   // (specialised path: no row remap)
+        // Through a buffer descriptor built per tile on the scalar unit (base = this wave's first row and column of the residual, size = up to
+        // the last valid row: rows past M read as zero and are never stored): one per-lane offset for all 16 chunks plus a scalar row offset -
+        // no per-chunk 64-bit address arithmetic, no clamps (16 hoisted row addresses used to cost the residual flavours their registers).
+        const int ldrb = PF == 1 ? __builtin_amdgcn_readfirstlane((int)e.ldr * 2) : 0;   // (host: ldr < 2^22)
+        __amdgpu_buffer_rsrc_t rrsrc;
+        if constexpr (PF == 1) {
+            const int64_t row0r = em0 + wm * 128;
+            const int64_t leftr = g.M - row0r;
+            const int rows_r = leftr >= 128 ? 128 : (leftr > 0 ? (int)leftr : 0);
+            rrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((char*)e.res + (row0r * e.ldr + en0 + wn * 64) * 2), 0,
+                                                      __builtin_amdgcn_readfirstlane(rows_r ? (rows_r - 1) * ldrb + 128 : 0), 0x00020000);
+        }
+        auto load_res = [&](int qu, int rvoff) {   // chunk qu of this lane: row (qu >> 1) * 16 + (qu & 1) * 8 + crow, columns (lane & 7) * 8 ..
+            return __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rvoff + ((qu >> 1) * 16 + (qu & 1) * 8) * ldrb, 0, 0);   // (row offset in the checked VECTOR offset)
         };
         if constexpr (PF == 1) {
+            const int rvoff = crow * ldrb + (lane_e & 7) * 16;
 #pragma unroll
-            for (int qu = 0; qu < 8; ++qu) rpre[qu] = load_res(qu, crow, n);
+            for (int qu = 0; qu < 8; ++qu) rpre[qu] = load_res(qu, rvoff);
         }
         if constexpr (PF == 2) {
 #pragma unroll
@@ -485,7 +517,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         }
         float* cst = (float*)(smem + 2 * STAGE_BYTES + 6144);   // bias[256] | colsum[256]: a gap in the epilogue region the strips leave free
         if constexpr (T16) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (the column constant was requested before the last K-tile; the residual flavours' first batch of 8 chunks, requested just
+            // above, is younger and stays in flight: it is first needed two strips into the epilogue)
+            if constexpr (PF == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("" : "+v"(cpre));
             cst[tid] = cpre;
         }
@@ -512,13 +547,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         // definitions as complete: otherwise it guards every use inside the store loop with a conservative vmcnt(0) (it
         // cannot count the stores of the branchy store code; vmcnt retires loads and stores in order, so each such wait
         // would drain the previous pass's stores - 16 store round trips per tile instead of one load round trip).
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(T16 && PF == 1)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (T16 residual flavour: waited for at its first use)
 #pragma unroll
         for (int c = 0; c < 8; ++c) { asm volatile("" : "+v"(b8[c])); asm volatile("" : "+v"(s8[c])); }
-        if constexpr (PF == 1) {
-#pragma unroll
-            for (int qu = 0; qu < 8; ++qu) asm volatile("" : "+v"(rpre[qu]));
-        }
         if constexpr (PF == 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) asm volatile("" : "+v"(lnpre[u]));
@@ -545,7 +576,12 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             // as packed pairs - one ds_write_b64 per (row, 4 columns), 1.5 LDS-write cycles per value instead of the 4 of
             // fp32 ds_write_b32 - in two alternating 16 x 128 B strips (row pitch 136 B: the 16 lanes of a write hit 16
             // distinct bank pairs), and re-read row-major, 16 bytes per lane, straight into the global stores.
-            constexpr int ACT = CFG & 1;
+            // Residual flavours (PF == 1; round 4, before: fp32 strips, 64 ds_write_b32 per strip): the 16-bit residual chunks sit in registers
+            // in the READ-BACK layout (8 lanes per row, 8 columns each: the layout of the stores), so the residual is added after the
+            // read-back - float(branch value rounded to T) + float(residual), rounded to T: the reference's own two roundings in half
+            // precision (clip/model.py:225-228) and the arithmetic of epi_chunk8 (both GEMM families: bit-identical) - and the row's
+            // LayerNorm partials (STATS) come from those stored values there too, with epi_chunk8's additions in epi_chunk8's order.
+            constexpr int ACT = CFG & 1, STATS = (CFG >> 1) & 1;
             typedef typename VecOf<T>::v4 v4t;
             typedef typename VecOf<T>::v8 v8t;
             drain = true;
@@ -554,8 +590,8 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                 char* st = smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES);
                 // Output stores go through a buffer descriptor rebuilt per tile on the scalar unit: base = this wave's first row and
                 // column, size = up to the last valid row - rows past M fall outside and the hardware drops their stores, so edge
-                // tiles run the same code with the same store count - and every store is (per-lane offset, scalar row offset):
-                // no 64-bit per-lane address arithmetic in the passes (it was 56 % of the vector instructions of this epilogue).
+                // tiles run the same code with the same store count - and every store is one 32-bit per-lane offset (row offset included:
+                // the bounds check looks at the vector offset only): no 64-bit per-lane address arithmetic in the passes.
                 const int64_t row0 = em0 + wm * 128;
                 const int64_t left = g.M - row0;
                 const int rows_ok = left >= 128 ? 128 : (left > 0 ? (int)left : 0);
@@ -563,6 +599,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                 const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
                     uniform_ptr((char*)e.out + (row0 * e.ldy + en0 + wn * 64) * 2), 0,
                     __builtin_amdgcn_readfirstlane(rows_ok ? (rows_ok - 1) * ldb + 128 : 0), 0x00020000);
+                __amdgpu_buffer_rsrc_t srsrc;
+                if constexpr (STATS == 1)
+                    srsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        uniform_ptr((char*)e.stats_out + ((int64_t)((en0 + wn * 64) >> 6) * e.stats_rows + row0) * 8), 0,
+                        __builtin_amdgcn_readfirstlane(rows_ok * 8), 0x00020000);
                 // LayerNorm (mean, rstd) of strip q's rows: lane (m, g = q >> 1) holds them in lnpre[q & 1]
                 auto fetch_ln = [&](int q, float& mean, float& rstd) {
                     if constexpr (PF == 2) {
@@ -605,6 +646,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                     asm volatile("" : "+v"(lane_q));
                     const int crow = lane_q >> 3, c16 = (lane_q & 7) * 16;
                     const int voff = crow * ldb + c16;
+                    const int svoff = (lane_q & 7) < 2 ? ((lane_q & 1) * 8 + crow) * 8 : 0x7ff00000;
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const char* sp = st + (q & 1) * STRIP + crow * PITCH + c16;
@@ -619,95 +661,44 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                         v8t o0, o1;
 #pragma unroll
                         for (int c = 0; c < 4; ++c) { o0[c] = r0[c]; o0[4 + c] = r1[c]; o1[c] = r2[c]; o1[4 + c] = r3[c]; }
+                        if constexpr (PF == 1) {
+                            if (q == 0) {
+                                // second residual batch: issued with the first two strips parked (their 32 accumulator registers are free) and
+                                // before any store of this tile; then the first batch - older than it and than the next tile's LDS-DMA pieces
+                                // issued above - must be in: all but the 8 youngest operations
+                                const int rvoff = crow * ldrb + c16;
+#pragma unroll
+                                for (int qu = 8; qu < 16; ++qu) rpre[qu] = load_res(qu, rvoff);
+                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#pragma unroll
+                                for (int qu = 0; qu < 8; ++qu) asm volatile("" : "+v"(rpre[qu]));
+                            }
+                            if (q == 4) {   // the second batch is needed from here on: everything but the stores issued since must be back
+                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + STATS)) : "memory");
+#pragma unroll
+                                for (int qu = 8; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
+                            }
+                            const v8t ra = __builtin_bit_cast(v8t, rpre[PF == 1 ? 2 * q : 0]), rb = __builtin_bit_cast(v8t, rpre[PF == 1 ? 2 * q + 1 : 0]);
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) { o0[c] = (T)((float)o0[c] + (float)ra[c]); o1[c] = (T)((float)o1[c] + (float)rb[c]); }
+                        }
                         if (decltype(nostore)::value && (float)o0[0] != 12345.678f) continue;
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o0), orsrc, voff, (q * 16) * ldb, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o1), orsrc, voff, (q * 16 + 8) * ldb, 0);
+                        // (the row offset travels in the VECTOR offset: only that one is bounds-checked - the scalar offset of a buffer access is
+                        // excluded from the range check, and round 3's stores, which carried the row offset there, were NOT clipped on edge tiles)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o0), orsrc, voff + (q * 16) * ldb, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o1), orsrc, voff + (q * 16 + 8) * ldb, 0, 0);
+                        if constexpr (STATS == 1) {
+                            // LayerNorm partials, slot-major [slot][row][2]: the pass's 16 rows are 128 contiguous bytes of this wave's slot;
+                            // lane (row r, 0) stores the pair of row r, lane (row r, 1) the pair of row r + 8 - ONE full-line store per pass,
+                            // through a descriptor that ends at the last valid row (lanes 2 .. 7 of a row carry an offset past its end: dropped)
+                            const f32x2 sa = row_block_stats(o0), sb = row_block_stats(o1);
+                            typedef __attribute__((ext_vector_type(2))) int i32x2;
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, (lane_q & 1) ? sb : sa), srsrc, svoff + q * 128, 0, 0);
+                        }
                     }
                 };
                 if (DIAG(g.dbg) & 2) passes16(BoolC<true>{});
                 else { passes16(BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
-            } else if (p.acc[0][0][0][0] == 12345.678f) {
-                ((float*)e.out)[0] = 1.f;
-            }
-        } else if constexpr (CFG >= 0) {
-            // Specialised epilogue.  The wave parks 16x64 fp32 strips alternately in two private 4 KiB buffers (strip
-            // q+1 is written before strip q is read back, so the LDS write->read round trip of one strip hides behind
-            // the other's arithmetic and stores).  The 64 KiB come from the epilogue region plus the k1 slots of
-            // stage 1, which the next tile's prologue does not touch.
-            drain = true;
-            if (!(DIAG(g.dbg) & 1)) {
-                constexpr int ACT = CFG & 1, STATS = (CFG >> 1) & 1;
-                float* st = (float*)(smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES));
-                const int wsw = ((lane_e >> 4) & 1) << 4;
-                const int wr_off = 4 * (lane_e >> 4) * 64 + (lane_e & 15);
-                auto park = [&](int q) {
-                    float* sq = st + (q & 1) * (EPI_WAVE_BYTES / 4) + wr_off;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) sq[r * 64 + ((16 * j) ^ wsw)] = p.acc[q >> 2][q & 3][j][r];
-                };
-                auto passes = [&](auto check, auto nostore) {
-                    park(0);
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        if (q + 1 < 8) park(q + 1);
-                        // Row / column addressing is rebuilt in every pass from a laundered lane id (a dozen VALU
-                        // instructions): kept across the passes - or hoisted out of the persistent loop - the 64-bit
-                        // pointers do not fit beside the accumulators and get spilled to scratch.
-                        int lane_q = lane_e;
-                        asm volatile("" : "+v"(lane_q));
-                        const int crow = lane_q >> 3, ccol = (lane_q & 7) * 8;
-                        const int n = en0 + wn * 64 + ccol;
-                        const int64_t row_base = em0 + wm * 128 + crow;
-                        T* optr = (T*)e.out + row_base * e.ldy + n;
-                        // LayerNorm partials, slot-major [slot][row][2]: the pass's 16 rows are 128 contiguous bytes of this wave's slot;
-                        // lane (row r, 0) stores the pair of row r, lane (row r, 1) the pair of row r + 8 - ONE full-line store per pass
-                        f32x2 st2[2] = {{0.f, 0.f}, {0.f, 0.f}};
-                        const int rd_off[2] = {crow * 64 + (ccol ^ (((crow >> 2) & 1) << 4)), (8 + crow) * 64 + (ccol ^ ((((8 + crow) >> 2) & 1) << 4))};
-                        if constexpr (PF == 1) {
-                            if (q == 0) {   // second residual batch: issued before any store of this tile
-#pragma unroll
-                                for (int qu = 8; qu < 16; ++qu) rpre[qu] = load_res(qu, crow, n);
-                            }
-                            if (q == 4) {   // ... and needed from here on: everything but the stores issued since must be back
-                                if (decltype(check)::value) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (store count varies)
-                                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + STATS)) : "memory");
-#pragma unroll
-                                for (int qu = 8; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
-                            }
-                        }
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {
-                            const float* sp = st + (q & 1) * (EPI_WAVE_BYTES / 4) + rd_off[u];
-                            const f32x4 v0 = *(const f32x4*)sp, v1 = *(const f32x4*)(sp + 4);
-                            const int roff = q * 16 + u * 8;
-                            if (decltype(check)::value && row_base + roff >= g.M) continue;
-                            float vv[8];
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) { vv[c] = v0[c]; vv[4 + c] = v1[c]; }
-                            if (decltype(nostore)::value && vv[0] != 12345.678f) continue;
-                            f32x2 ln = lnpre[0];
-                            if constexpr (PF == 2) {
-                                const int src = ((lane_q & ~7) | q) << 2;   // byte address of the source lane
-                                // (scalar copies first: __builtin_bit_cast applied to a vector ELEMENT reads element 0 with this hipcc)
-                                const float mean_l = lnpre[u][0], rstd_l = lnpre[u][1];
-                                ln[0] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(mean_l)));
-                                ln[1] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(rstd_l)));
-                            }
-                            epi_fast_chunk<T, PF, ACT, STATS>(vv, b8, s8, rpre[PF == 1 ? q * 2 + u : 0], ln, optr + (int64_t)roff * e.ldy, st2[u]);
-                        }
-                        if constexpr (STATS == 1) {
-                            const int sel = lane_q & 7;
-                            const int64_t srow = row_base + q * 16 + (sel & 1) * 8;
-                            if (sel < 2 && (!decltype(check)::value || srow < g.M) && !decltype(nostore)::value)
-                                *(f32x2*)(e.stats_out + ((int64_t)(n >> 6) * e.stats_rows + srow) * 2) = sel ? st2[1] : st2[0];
-                        }
-                    }
-                };
-                if (DIAG(g.dbg) & 2) passes(BoolC<true>{}, BoolC<true>{});
-                else if (em0 + TM <= g.M) { passes(BoolC<false>{}, BoolC<false>{}); drain = DIAG(g.strict_wait) != 0; }
-                else passes(BoolC<true>{}, BoolC<false>{});
             } else if (p.acc[0][0][0][0] == 12345.678f) {
                 ((float*)e.out)[0] = 1.f;
             }
@@ -750,11 +741,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #endif
 }
 
-template <typename T, int PF, int CFG>
+template <typename T, int PF, int CFG, bool IM2COL = false>
 int launch256_pf(const Gemm256Args& a, int grid, hipStream_t s) {
     static bool attr_set[LECLIP_MAX_DEVICES] = {};
-    leclip_set_max_lds(gemm_tn_256x256x64_pp<T, PF, CFG>, LDS_BYTES, attr_set);
-    hipLaunchKernelGGL((gemm_tn_256x256x64_pp<T, PF, CFG>), dim3(grid), dim3(512), LDS_BYTES, s, a);
+    leclip_set_max_lds((gemm_tn_256x256x64_pp<T, PF, CFG, IM2COL>), LDS_BYTES, attr_set);
+    hipLaunchKernelGGL((gemm_tn_256x256x64_pp<T, PF, CFG, IM2COL>), dim3(grid), dim3(512), LDS_BYTES, s, a);
     return leclip_check_launch("gemm_tn_256x256x64_pp");
 }
 
@@ -780,6 +771,10 @@ int launch256(const Gemm256Args& a, hipStream_t s) {
     // (leading dimensions below 2^22 elements: the specialised epilogues address a tile's rows with 32-bit buffer offsets)
     const bool fast_ok = !force_generic && e.out_dt == tdt && !e.rowmap_P && (!e.res || e.res_dt == tdt) && !(e.res && ln) &&
                          e.ldy < (1 << 22) && e.ldr < (1 << 22);
+    if (a.im_R) {   // im2col-free patch embedding: only the plain 16-bit epilogue exists in this form (checked by the caller)
+        if (!fast_ok || e.res || ln || e.stats_out || e.act != LECLIP_ACT_NONE) { leclip_set_error("gemm(im2col): unsupported epilogue"); return LECLIP_E_UNSUPPORTED; }
+        return launch256_pf<T, 0, 0, true>(a, grid, s);
+    }
     if (fast_ok) {
         const bool gelu = e.act == LECLIP_ACT_QUICKGELU, stats = e.stats_out != nullptr;
         if (!e.res && !ln && !stats) return gelu ? launch256_pf<T, 0, 1>(a, grid, s) : launch256_pf<T, 0, 0>(a, grid, s);
@@ -830,6 +825,7 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
     a.tiles_total = (int)(tiles_m * a.tiles_n);
     a.dbg = a.desync = a.no_xtile = a.strict_wait = 0;
+    a.im_R = a.im_G = 0;
     a.stamps = nullptr;
 #ifdef LECLIP_DIAG
     static const int dbg = [] { const char* e = getenv("LECLIP_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
@@ -842,6 +838,33 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.no_xtile = no_xtile;
     static const int strict_wait = [] { const char* e = getenv("LECLIP_GEMM_STRICT_WAIT"); return e ? atoi(e) : 0; }();
     a.strict_wait = strict_wait;
+#endif
+    return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
+}
+
+// Patch-embedding GEMM without a patch matrix (clip/model.py:247, 260: Conv2d(3, width, kernel 16, stride 16, bias=False) as
+// [B G^2, 768] x [width, 768]^T): A tiles are gathered from the NCHW image by the LDS-DMA source addresses (PP<.., IM2COL>).  Takes 16-bit
+// images in the weights' dtype, 16 x 16 patches, R % 8 == 0 (16-byte source chunks), and the shapes the 256 x 256 kernel takes.
+bool leclip_gemm256_im2col_eligible(int64_t B, int R, int P, int N, int img_dtype, int w_dtype, const void* image) {
+    if (P != 16 || R % 16 != 0 || img_dtype != w_dtype || w_dtype == LECLIP_F32 || ((uintptr_t)image & 15)) return false;
+    const int64_t G = R / P;
+    return leclip_gemm256_eligible(B * G * G, N, 3 * P * P);
+}
+
+int leclip_gemm256_launch_im2col(const void* image, const void* W, int64_t B, int R, int N, int64_t ldw, const EpiParams& epi, int ab_dtype,
+                                 hipStream_t s) {
+    Gemm256Args a;
+    const int G = R / 16;
+    a.A = image; a.W = W; a.M = B * G * G; a.N = N; a.K = 768; a.lda = 0; a.ldw = ldw; a.epi = epi;
+    const int64_t tiles_m = (a.M + TM - 1) / TM;
+    a.tiles_n = N / TN;
+    if (tiles_m * a.tiles_n > 0x7fffffff || B * 3 * (int64_t)R * R > 0x7fffffffLL * 4) { leclip_set_error("gemm(im2col): too large"); return LECLIP_E_UNSUPPORTED; }
+    a.tiles_total = (int)(tiles_m * a.tiles_n);
+    a.dbg = a.desync = a.no_xtile = a.strict_wait = 0;
+    a.im_R = R; a.im_G = G;
+    a.stamps = nullptr;
+#ifdef LECLIP_DIAG
+    a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
 #endif
     return ab_dtype == LECLIP_BF16 ? launch256<bf16_t>(a, s) : launch256<f16_t>(a, s);
 }

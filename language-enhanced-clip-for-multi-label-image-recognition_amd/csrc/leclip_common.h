@@ -192,6 +192,19 @@ __device__ __forceinline__ void epi_chunk8(const EpiParams& e, int64_t m, int n,
     }
     int64_t orow = m, rrow = m;
     if (e.rowmap_P) { orow = m + m / e.rowmap_P + 1; rrow = m % e.rowmap_P + 1; }
+    // Residual in the OUTPUT's 16-bit type (the residual stream of the 16-bit modes): the branch value is rounded to that type before the
+    // residual is added - the reference's own order in half precision (clip/model.py:225-228: F.linear returns a 16-bit tensor, `x + ...`
+    // is a second 16-bit operation) and, since round 4, what lets the 256 x 256 kernel stage the branch value through LDS in 16 bits
+    // (gemm_mfma256.hip, T16 epilogue) with results that stay bit-identical to this code.  fp32 outputs / residuals: no extra rounding.
+    if ((MODE == 1 || (MODE == 3 && e.res)) && e.out_dt != LECLIP_F32 && e.res_dt == e.out_dt) {
+        if (e.out_dt == LECLIP_BF16) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (float)(bf16_t)v[c];
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] = (float)(f16_t)v[c];
+        }
+    }
     if (MODE == 1 || (MODE == 3 && e.res)) {
         if (MODE == 3 && e.res_dt == LECLIP_F32) {
             const float* rp = (const float*)e.res + rrow * e.ldr + n;
@@ -264,49 +277,25 @@ __device__ __forceinline__ float row8_sum(float x) {
     return x;
 }
 
-// Compile-time-specialised 8-wide epilogue step (the hot configurations: output and residual in the operand dtype T, no
-// row remap).  Same arithmetic, in the same order, as epi_chunk8 (leclip_common.h); no branches, no address arithmetic
-// beyond the pointer handed in, row sums by DPP; STATS: the row's (sum, M2 about the block mean) comes back in `stat`.
-template <typename T, int PF, int ACT, int STATS>
-__device__ __forceinline__ void epi_fast_chunk(float (&v)[8], const float (&b8)[8], const float (&s8)[8], i32x4 res_val,
-                                               f32x2 ln_val, T* optr, f32x2& stat) {
-    typedef typename VecOf<T>::v8 v8;
-    if constexpr (PF == 2) {
-        const float mean = ln_val[0], rstd = ln_val[1];
+// (sum, M2 about the block mean) of one output row's 64-column block from the 8 rounded values each of the row's 8 consecutive lanes
+// holds - the LayerNorm partials a producing GEMM emits.  M2 about the BLOCK mean, so that a large common offset of the row never enters a
+// difference of two large sums (the consumer merges the blocks with the parallel-variance update).  Same additions, in the same order,
+// as the butterfly in epi_chunk8: the two GEMM families emit identical partials.  Every one of the 8 lanes returns the pair.
+template <typename V8>
+__device__ __forceinline__ f32x2 row_block_stats(const V8& o8) {
+    float s1 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = fmaf(rstd, fmaf(-mean, s8[c], v[c]), b8[c]);
-    } else {
+    for (int c = 0; c < 8; ++c) s1 += (float)o8[c];
+    s1 = row8_sum(s1);
+    const float mb = s1 * (1.0f / 64.0f);
+    float m2 = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += b8[c];
-    }
-    if constexpr (ACT == 1) {
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] = v[c] * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v[c]));
-    }
-    if constexpr (PF == 1) {
-        const v8 r8 = __builtin_bit_cast(v8, res_val);
-#pragma unroll
-        for (int c = 0; c < 8; ++c) v[c] += (float)r8[c];
-    }
-    v8 o8;
-#pragma unroll
-    for (int c = 0; c < 8; ++c) o8[c] = (T)v[c];
-    *(v8*)optr = o8;
-    if constexpr (STATS == 1) {
-        // (sum, centred sum of squares) of the 64-column block: M2 about the BLOCK mean, so that a large common offset of the
-        // row never enters a difference of two large sums (the consumer merges the blocks with the parallel-variance update)
-        float s1 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) s1 += (float)o8[c];
-        s1 = row8_sum(s1);
-        const float mb = s1 * (1.0f / 64.0f);
-        float m2 = 0.f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) { const float dlt = (float)o8[c] - mb; m2 = fmaf(dlt, dlt, m2); }
-        m2 = row8_sum(m2);
-        stat[0] = s1;       // every one of the row's 8 lanes holds the pair; the caller stores two rows' pairs with one instruction
-        stat[1] = m2;
-    }
+    for (int c = 0; c < 8; ++c) { const float dlt = (float)o8[c] - mb; m2 = fmaf(dlt, dlt, m2); }
+    m2 = row8_sum(m2);
+    f32x2 st;
+    st[0] = s1;
+    st[1] = m2;
+    return st;
 }
 
 template <bool PRECISE>

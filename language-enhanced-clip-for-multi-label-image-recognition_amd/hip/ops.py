@@ -145,7 +145,7 @@ def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, 
         out = torch.empty((b, t, width), dtype=x_dtype, device=image.device)
     npatch = b * (t - 1)
     with _Timed("patch_embed", 2 * npatch * width * 3 * patch * patch,
-                image.numel() * image.element_size() + npatch * wp.shape[1] * wp.element_size() * 2 + b * t * width * out.element_size()):
+                image.numel() * image.element_size() + wp.numel() * wp.element_size() + b * t * width * out.element_size()):   # ALGORITHMIC bytes: image in, weights, tokens out
         _capi.check(_capi.load().leclip_patch_embed_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(out), b, r,
                                                         patch, width, dtype_code(image.dtype), dtype_code(wp.dtype),
                                                         dtype_code(out.dtype), _ptr(workspace), _stream()), "patch_embed")
@@ -155,8 +155,9 @@ def patch_embed(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, 
 def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tensor, pos: torch.Tensor, gamma: torch.Tensor,
                    beta: torch.Tensor, patch: int, x_dtype: torch.dtype, workspace: Optional[torch.Tensor] = None,
                    out: Optional[torch.Tensor] = None, eps: float = 1e-5, stats_out: Optional[torch.Tensor] = None):
-    """ln_pre(patch embedding) in three launches: patch extraction, conv GEMM (plain fast epilogue), fused class-token /
-    positional add / LayerNorm pass (leclip_patch_embed_ln_fwd)."""
+    """ln_pre(patch embedding) (leclip_patch_embed_ln_fwd): conv GEMM (plain fast epilogue), then the fused class-token / positional add /
+    LayerNorm pass.  Images in the compute dtype with 16 x 16 patches and a batch that fills the 256 x 256 GEMM kernel are gathered by that
+    kernel's LDS-DMA straight from NCHW (two launches, no patch matrix); anything else goes through a patch-extraction kernel first."""
     _dev(image, "image")
     b, c, r, r2 = image.shape
     if c != 3 or r != r2 or not image.is_contiguous():
@@ -171,7 +172,7 @@ def patch_embed_ln(image: torch.Tensor, wp: torch.Tensor, class_emb: torch.Tenso
         out = torch.empty((b, t, width), dtype=x_dtype, device=image.device)
     npatch = b * (t - 1)
     with _Timed("patch_embed", 2 * npatch * width * 3 * patch * patch,
-                image.numel() * image.element_size() + npatch * wp.shape[1] * wp.element_size() * 2 + 3 * b * t * width * out.element_size()):
+                image.numel() * image.element_size() + wp.numel() * wp.element_size() + b * t * width * out.element_size()):   # ALGORITHMIC bytes only (no intermediates)
         _capi.check(_capi.load().leclip_patch_embed_ln_fwd(_ptr(image), _ptr(_dev(wp, "wp")), _ptr(class_emb), _ptr(pos), _ptr(_dev(gamma, "gamma")),
                                                            _ptr(_dev(beta, "beta")), _ptr(out), _ptr(stats_out), b, r, patch, width, dtype_code(image.dtype),
                                                            dtype_code(wp.dtype), dtype_code(out.dtype), eps, _ptr(workspace), _stream()),

@@ -179,6 +179,55 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm256_edge_tiles_write_nothing_past_m(ops, dt):
+    """The specialised epilogues store through buffer descriptors that end at the last valid row; the hardware must drop what an edge tile
+    (M % 256 != 0) holds past it.  Round 3 carried the row offset in the SCALAR offset of those stores, which the bounds check does not look
+    at: rows past M were written (up to 255 rows beyond the output, found in round 4 when the residual flavours moved to the same stores).
+    Outputs are views of larger buffers here whose tail rows hold a sentinel: every flavour must leave them untouched, bit for bit."""
+    M, N, K = 6160, 2048, 512            # 24 full tile rows + 16 valid rows in the last one; 200 tiles: one per workgroup
+    g = torch.Generator(device="cpu").manual_seed(11)
+    a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
+    bias = torch.randn(N, generator=g).to(DEV)
+    stats = torch.stack([torch.randn(M, generator=g) * 0.1, torch.rand(M, generator=g) + 0.5], dim=1).contiguous().to(DEV)
+    colsum = torch.randn(N, generator=g).to(DEV)
+    pad = 300
+    sentinel = 1234.0
+
+    def guarded():
+        buf = torch.full((M + pad, N), sentinel, dtype=dt, device=DEV)
+        return buf, buf[:M]
+
+    def untouched(buf):
+        return bool((buf[M:] == sentinel).all())
+
+    buf, out = guarded()
+    ops.gemm(a, w, bias, out=out)
+    assert untouched(buf), "plain epilogue wrote past M"
+    buf, out = guarded()
+    ops.gemm(a, w, bias, act=ops.ACT_QUICKGELU, out=out)
+    assert untouched(buf), "QuickGELU epilogue wrote past M"
+    buf, out = guarded()
+    ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, out=out)
+    assert untouched(buf), "fused-LayerNorm epilogue wrote past M"
+    # residual flavours, in place (the residual stream x is updated by out-proj / c_proj): x lives in the guarded buffer too
+    buf, out = guarded()
+    res0 = torch.randn(M, N, generator=g).to(dt).to(DEV)
+    out.copy_(res0)
+    ops.gemm(a, w, bias, residual=out, out=out)
+    assert untouched(buf), "residual epilogue wrote past M"
+    ref = (a.float() @ w.float().t() + bias).to(dt).float() + res0.float()
+    assert float((out.float() - ref).abs().max()) <= (6e-2 if dt == torch.bfloat16 else 8e-3) * float(ref.abs().max())
+    buf, out = guarded()
+    out.copy_(res0)
+    part_buf = torch.full((N // 64, M, 2), sentinel, dtype=torch.float32, device=DEV)
+    ops.gemm_ln(a, w, bias, residual=out, stats_out=part_buf, out=out)
+    assert untouched(buf), "residual + partials epilogue wrote past M"
+    yy = out.float().view(M, N // 64, 64)
+    assert float((part_buf.permute(1, 0, 2)[..., 0] - yy.sum(-1)).abs().max()) <= 1e-3     # every (slot, row) pair written, none from a row past M
+
+
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm_families_are_bit_identical(ops, dt):
     """Which GEMM kernel family a call takes depends on M (256x256 persistent kernel when the grid fills the chip, 128x128
     otherwise).  Both feed v_mfma_f32_16x16x32 the same ascending K sequence and share the epilogue arithmetic, so a
@@ -351,6 +400,34 @@ def test_patch_embed(ops, dt, geom):
     np.testing.assert_allclose(x.float().cpu().numpy(), ref.numpy(), atol=_tol(dt, 1e-5, 6e-3, 5e-2), rtol=0)
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("batch", [96, 85])
+def test_patch_embed_im2col_free(ops, dt, batch):
+    """Round 4: images handed over in the compute dtype take the im2col-free patch GEMM (the 256 x 256 kernel gathers its A tiles from the
+    NCHW image by LDS-DMA, no patch matrix: csrc/gemm_mfma256.hip PP<.., IM2COL>) once the batch fills that kernel (B >= 84 at 224 x 224).
+    The same pixel values handed over as fp32 take the older path (patch-extraction kernel, then the same GEMM on a patch matrix): both
+    must produce the residual stream and its LayerNorm partials BIT FOR BIT, and match ln_pre(patch_embed) of the oracle.  B = 85: a
+    last tile row that is partly past M (clamped gather rows, clipped stores)."""
+    from oracle import clip_oracle as co
+    r, p, width = 224, 16, 768
+    img16 = _rand((batch, 3, r, r), 31).to(dt)
+    w = _rand((width, 3, p, p), 32, (3 * p * p) ** -0.5).to(dt)
+    cls, pos = _rand((width,), 33), _rand(((r // p) ** 2 + 1, width), 34)
+    gamma, beta = 1 + 0.1 * _rand((width,), 35), 0.1 * _rand((width,), 36)
+    wp = w.reshape(width, 3 * p * p).contiguous().to(DEV)
+    args = (wp, cls.to(DEV), pos.to(DEV), gamma.to(DEV), beta.to(DEV), p, dt)
+    t = (r // p) ** 2 + 1
+    st_a = torch.zeros((width // 64, batch * t, 2), dtype=torch.float32, device=DEV)
+    st_b = torch.zeros_like(st_a)
+    xa = ops.patch_embed_ln(img16.to(DEV), *args, stats_out=st_a)                    # compute-dtype image: im2col-free
+    xb = ops.patch_embed_ln(img16.float().to(DEV), *args, stats_out=st_b)            # same values as fp32: patch matrix + GEMM
+    assert xa.dtype == dt and torch.equal(xa, xb) and torch.equal(st_a, st_b)
+    sd = {"visual.conv1.weight": w.float(), "visual.class_embedding": cls, "visual.positional_embedding": pos}
+    sel = torch.tensor([0, 1, batch // 2, batch - 1])
+    ref = co.layer_norm(co.patch_embed(img16[sel].float(), sd), gamma, beta)
+    np.testing.assert_allclose(xa[sel].float().cpu().numpy(), ref.numpy(), atol=_tol(dt, 1e-5, 1.5e-2, 1e-1), rtol=0)
+
+
 # --------------------------------------------------------------------------------- towers against the oracle / golden
 def _build(arch, seed, dist, dtype):
     from leclip_amd.clip import build_model, convert_weights
@@ -450,7 +527,9 @@ def test_vitb16_outlier_golden(ops, golden_dir, dt):
         lcc = cc(img, if_test=True)[0].float().cpu().numpy()
     err_cc = float(np.abs(lcc - g["logits_custom_ctx16"]).max())
     print(f"outlier weights [{dt}]: max|dlogit| CLIP (scale 14.3) {err:.3e}, CustomCLIP (scale 4) {err_cc:.3e}")
-    assert err <= _tol(dt, 1e-3, 3e-2, 2.5e-1) and err_cc <= _tol(dt, 1e-3, 8e-3, 7e-2), (err, err_cc)
+    # measured (round 4): fp32 3.8e-5 / 5.5e-6, fp16 2.3e-2 / 2.7e-3, bf16 2.3e-1 / 2.2e-2 - the same error per unit of logit scale as on the benign
+    # weight sets; bounds = 2 x measured (fp32: the north star's 1e-3)
+    assert err <= _tol(dt, 1e-3, 4.6e-2, 4.6e-1) and err_cc <= _tol(dt, 1e-3, 5.5e-3, 4.5e-2), (err, err_cc)
     if dt == torch.float32:
         assert np.array_equal(np.argsort(-lpi, axis=1, kind="stable")[:, :5], g["top5_clip"])
         assert np.array_equal(np.argsort(-lcc, axis=1, kind="stable")[:, :5], g["top5_custom_ctx16"])
@@ -507,7 +586,10 @@ def test_cfg4_logits_against_the_reference_at_size(ops, golden_dir, dt):
     elif dt == torch.float16:
         assert abs(m_hip - m_ref) <= 0.2                 # the north star's clause, at size, against the reference
     else:
-        assert abs(m_hip - m_ref) <= 0.35                # bf16: measured (round 4) - see DESIGN section 3 for the decision this number backs
+        # bf16: measured -0.254 at N = 2 048 against the reference (round 4; max |dlogit| 3.2e-2, 56 near-tie flips): it does NOT meet the
+        # +-0.2 clause, with the sampling noise of the 192-image samples gone - DESIGN.md section 3: bf16 is the rate-only companion dtype, the
+        # clause is claimed for fp16 (the reference's own GPU precision).  The bound here only guards the kernels against a regression.
+        assert abs(m_hip - m_ref) <= 0.4
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -608,7 +690,7 @@ def test_full_batch_properties(ops, dt):
             assert torch.equal(cc(img[256 - n:].contiguous(), if_test=True)[0], full[256 - n:])
 
 
-@pytest.mark.parametrize("dt,tol,claim", [(torch.float16, 0.2, "north-star clause"), (torch.bfloat16, 0.6, "regression bound only")])
+@pytest.mark.parametrize("dt,tol,claim", [(torch.float16, 0.2, "north-star clause"), (torch.bfloat16, 0.6, "regression bound only (the clause is settled at N = 2048 by test_cfg4_logits_against_the_reference_at_size: -0.25, not met)")])
 def test_map_against_oracle(ops, dt, tol, claim):
     """mAP over 80 labels of the HIP logits vs the fp32 CPU oracle's on the same 256 images, labels drawn from the
     oracle logits.
@@ -1005,10 +1087,11 @@ def test_fused_layernorm_on_large_mean_rows(ops, dt):
         err_plain = float((plain.double().cpu() - ref).abs().max())
         scale = float(ref.abs().max())
         print(f"fused-LN [{dt}, {m}x{n}x{k}]: folded err {err:.3e}, unfused (layernorm -> gemm) err {err_plain:.3e}, max|ref| {scale:.2f}")
-        # bounds: 2 x the measured error of each path (round 4: fp16 folded 1.1e-3 / unfused 2.2e-3 of max|ref| ... see the printed line),
-        # and the folded form may not be worse than twice the unfused one
-        assert err <= (2.5e-2 if dt == torch.bfloat16 else 3.5e-3) * scale, (err, scale)
-        assert err <= 2.0 * err_plain + 1e-4 * scale, (err, err_plain)
+        # bounds: 2 x the measured error of the folded path as a fraction of max|ref| (round 4, MI355X: fp16 2.1e-4 / 2.3e-4, bf16 2.1e-3 /
+        # 1.6e-3 on the two shapes; the unfused path measured 4.5e-4 - 7.5e-4 and 3.4e-3 - 5.2e-3: the folded form is 2 - 3 x BETTER, it
+        # rounds gamma * W once instead of h and W), and the folded form may never be worse than the unfused one
+        assert err <= (4.5e-3 if dt == torch.bfloat16 else 5e-4) * scale, (err, scale)
+        assert err <= err_plain, (err, err_plain)
 
 
 def test_rccl_gather_path_single_rank(tmp_path):
