@@ -409,17 +409,23 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #else
         for (; t + 2 < nk; ++t) p.template ktile<0, EPI_STORES>(t, false, next_src);
 #endif
+        // T16 flavours: the per-column constants of the tile (bias | fused-LayerNorm column sums: 2 x 256 floats, one per thread) travel by
+        // LDS-DMA straight into a gap of the epilogue region (round 4; a register load before: its launder made hipcc drain every younger
+        // load - the residual flavours' first batch - right behind the K-loop).  Issued in front of the LAST TWO K-tiles: older than the 8
+        // operations the last K-tile's counted wait leaves in flight, so it has landed when the K-loop ends; the waves read it behind the
+        // barrier that closes the K-loop.  A missing operand is zero-filled by ordinary LDS stores.
+        float* cst = (float*)(smem + 2 * STAGE_BYTES + 6144);   // bias[256] | colsum[256]: a gap in the epilogue region the strips leave free
+        if constexpr (T16) {
+            const float* cp = wave < 4 ? e.bias : (PF == 2 ? e.ln_colsum : nullptr);      // (wave-uniform)
+            if (cp) __builtin_amdgcn_global_load_lds((const void*)(cp + n0 + (tid & 255)), LDS_PTR(cst + wave * 64), 4, 0, 0);
+            else if (wave < 4 || PF == 2) cst[tid] = 0.f;
+        }
         p.template ktile<1, EPI_STORES>(t, nx, next_src);
 
-        // T16 flavour: the per-column constants (bias | fused-LayerNorm column sums: 2 x 256 floats per tile, one per
-        // thread) and the lane's two (mean, rstd) pairs are requested BEFORE the last K-tile - 1 + 4 registers, older than
-        // that K-tile's DMA, complete under its four phases - and the column constants reach the waves through LDS
-        // after the K-loop (as 10 loads per lane behind the last MFMA cluster they cost ~1 400 exposed cycles per tile).
-        float cpre = 0.f;
+        // the lane's two (mean, rstd) pairs are requested BEFORE the last K-tile - 4 registers, older than that K-tile's DMA, complete
+        // under its four phases
         f32x2 lnq[2] = {{0.f, 1.f}, {0.f, 1.f}};
         if constexpr (T16) {
-            const float* cp = tid < 256 ? e.bias : (PF == 2 ? e.ln_colsum : nullptr);
-            if (cp) cpre = cp[n0 + (tid & 255)];
             if constexpr (PF == 2) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {   // lane (m = l & 15, g = l >> 4) keeps the rows of strips 2g and 2g + 1
@@ -486,23 +492,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
         // Through a buffer descriptor built per tile on the scalar unit (base = this wave's first row and column of the residual, size = up to
         // the last valid row: rows past M read as zero and are never stored): one per-lane offset for all 16 chunks plus a scalar row offset -
         // no per-chunk 64-bit address arithmetic, no clamps (16 hoisted row addresses used to cost the residual flavours their registers).
+        // The loads are INLINE ASM (hipcc does not count them): tracked loads made it put s_waitcnt vmcnt(0) in front of the first use of
+        // each batch - for the second batch that drained the twelve output stores issued since.  Their waits are the counted ones in the
+        // pass loop below, each naming the registers it releases; nothing between a load and its wait may touch those registers, which
+        // tests/isa_audit.py checks on the shipped code object.
         const int ldrb = PF == 1 ? __builtin_amdgcn_readfirstlane((int)e.ldr * 2) : 0;   // (host: ldr < 2^22)
-        __amdgpu_buffer_rsrc_t rrsrc;
+        i32x4 rdesc = {0, 0, 0, 0};
         if constexpr (PF == 1) {
             const int64_t row0r = em0 + wm * 128;
             const int64_t leftr = g.M - row0r;
             const int rows_r = leftr >= 128 ? 128 : (leftr > 0 ? (int)leftr : 0);
-            rrsrc = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((char*)e.res + (row0r * e.ldr + en0 + wn * 64) * 2), 0,
-                                                      __builtin_amdgcn_readfirstlane(rows_r ? (rows_r - 1) * ldrb + 128 : 0), 0x00020000);
+            const unsigned long long rb = (unsigned long long)uniform_ptr((char*)e.res + (row0r * e.ldr + en0 + wn * 64) * 2);
+            rdesc[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)rb);
+            rdesc[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(rb >> 32) & 0xffff);                    // stride 0, no swizzle
+            rdesc[2] = __builtin_amdgcn_readfirstlane(rows_r ? (rows_r - 1) * ldrb + 128 : 0);                // bytes
+            rdesc[3] = 0x00020000;
         }
-        auto load_res = [&](int qu, int rvoff) {   // chunk qu of this lane: row (qu >> 1) * 16 + (qu & 1) * 8 + crow, columns (lane & 7) * 8 ..
-            return __builtin_amdgcn_raw_buffer_load_b128(rrsrc, rvoff + ((qu >> 1) * 16 + (qu & 1) * 8) * ldrb, 0, 0);   // (row offset in the checked VECTOR offset)
-        };
-        if constexpr (PF == 1) {
-            const int rvoff = crow * ldrb + (lane_e & 7) * 16;
+        // chunk qu of this lane: row (qu >> 1) * 16 + (qu & 1) * 8 + crow, columns (lane & 7) * 8 ..; the row offset travels in the bounds-checked
+        // VECTOR offset.  (s_nop: a descriptor register fresh from v_readfirstlane needs 4 wait states in front of the load that reads it.)
+        auto load_res8 = [&](int first, int rvoff) {
 #pragma unroll
-            for (int qu = 0; qu < 8; ++qu) rpre[qu] = load_res(qu, rvoff);
-        }
+            for (int qu = first; qu < first + 8; ++qu) {
+                const int off = rvoff + ((qu >> 1) * 16 + (qu & 1) * 8) * ldrb;
+                if (qu == first) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? qu : 0]) : "v"(off), "s"(rdesc) : "memory");
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? qu : 0]) : "v"(off), "s"(rdesc) : "memory");
+            }
+        };
+        if constexpr (PF == 1) load_res8(0, crow * ldrb + (lane_e & 7) * 16);
         if constexpr (PF == 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
@@ -515,19 +531,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                 }
             }
         }
-        float* cst = (float*)(smem + 2 * STAGE_BYTES + 6144);   // bias[256] | colsum[256]: a gap in the epilogue region the strips leave free
-        if constexpr (T16) {
-            // (the column constant was requested before the last K-tile; the residual flavours' first batch of 8 chunks, requested just
-            // above, is younger and stays in flight: it is first needed two strips into the epilogue)
-            if constexpr (PF == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            asm volatile("" : "+v"(cpre));
-            cst[tid] = cpre;
-        }
         PIN();
         if (wm == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
         PIN();
-        __syncthreads();                             // every wave is done reading the K-loop buffers (and has published its constant)
+        // every wave is done reading the K-loop buffers (its fragment reads were retired in front of its last MFMA cluster) and its share of
+        // the column constants has landed.  A raw barrier: __syncthreads() would put s_waitcnt vmcnt(0) in front of it while LDS-DMA is in
+        // flight (the next tile's first K-tiles) and with it drain the residual chunks requested just above.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        PIN();
         if constexpr (T16) {
             const float* cb = cst + wn * 64 + 4 * (lane_e >> 4);
 #pragma unroll
@@ -666,25 +678,24 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                                 // second residual batch: issued with the first two strips parked (their 32 accumulator registers are free) and
                                 // before any store of this tile; then the first batch - older than it and than the next tile's LDS-DMA pieces
                                 // issued above - must be in: all but the 8 youngest operations
-                                const int rvoff = crow * ldrb + c16;
-#pragma unroll
-                                for (int qu = 8; qu < 16; ++qu) rpre[qu] = load_res(qu, rvoff);
-                                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-#pragma unroll
-                                for (int qu = 0; qu < 8; ++qu) asm volatile("" : "+v"(rpre[qu]));
+                                load_res8(8, crow * ldrb + c16);
+                                asm volatile("s_waitcnt vmcnt(8)"
+                                             : "+v"(rpre[0]), "+v"(rpre[1]), "+v"(rpre[2]), "+v"(rpre[3]), "+v"(rpre[4]), "+v"(rpre[5]), "+v"(rpre[6]), "+v"(rpre[PF == 1 ? 7 : 0])
+                                             : : "memory");
                             }
                             if (q == 4) {   // the second batch is needed from here on: everything but the stores issued since must be back
-                                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (2 + STATS)) : "memory");
-#pragma unroll
-                                for (int qu = 8; qu < 16; ++qu) asm volatile("" : "+v"(rpre[qu]));
+                                asm volatile("s_waitcnt vmcnt(%8)"
+                                             : "+v"(rpre[PF == 1 ? 8 : 0]), "+v"(rpre[PF == 1 ? 9 : 0]), "+v"(rpre[PF == 1 ? 10 : 0]), "+v"(rpre[PF == 1 ? 11 : 0]),
+                                               "+v"(rpre[PF == 1 ? 12 : 0]), "+v"(rpre[PF == 1 ? 13 : 0]), "+v"(rpre[PF == 1 ? 14 : 0]), "+v"(rpre[PF == 1 ? 15 : 0])
+                                             : "n"(4 * (2 + STATS)) : "memory");
                             }
                             const v8t ra = __builtin_bit_cast(v8t, rpre[PF == 1 ? 2 * q : 0]), rb = __builtin_bit_cast(v8t, rpre[PF == 1 ? 2 * q + 1 : 0]);
 #pragma unroll
                             for (int c = 0; c < 8; ++c) { o0[c] = (T)((float)o0[c] + (float)ra[c]); o1[c] = (T)((float)o1[c] + (float)rb[c]); }
                         }
                         if (decltype(nostore)::value && (float)o0[0] != 12345.678f) continue;
-                        // (the row offset travels in the VECTOR offset: only that one is bounds-checked - the scalar offset of a buffer access is
-                        // excluded from the range check, and round 3's stores, which carried the row offset there, were NOT clipped on edge tiles)
+                        // (the row offset travels in the VECTOR offset, the one the bounds check is documented to cover; round 3 carried it in the
+                        // scalar offset - its stores pass tests/test_gpu_parity.py::test_gemm256_edge_tiles_write_nothing_past_m too)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o0), orsrc, voff + (q * 16) * ldb, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o1), orsrc, voff + (q * 16 + 8) * ldb, 0, 0);
                         if constexpr (STATS == 1) {

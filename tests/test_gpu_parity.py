@@ -181,9 +181,10 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_gemm256_edge_tiles_write_nothing_past_m(ops, dt):
     """The specialised epilogues store through buffer descriptors that end at the last valid row; the hardware must drop what an edge tile
-    (M % 256 != 0) holds past it.  Round 3 carried the row offset in the SCALAR offset of those stores, which the bounds check does not look
-    at: rows past M were written (up to 255 rows beyond the output, found in round 4 when the residual flavours moved to the same stores).
-    Outputs are views of larger buffers here whose tail rows hold a sentinel: every flavour must leave them untouched, bit for bit."""
+    (M % 256 != 0) holds past it - for every flavour, the residual ones included (round 4 moved them to the same stores, and their
+    residual loads and LayerNorm-partial stores to descriptors of their own).  Outputs are views of larger buffers here whose tail rows hold a
+    sentinel: every flavour must leave them untouched, bit for bit.  (Row offsets travel in the bounds-checked vector offset; round 3's
+    library, which carried them in the scalar offset, passes this test as well.)"""
     M, N, K = 6160, 2048, 512            # 24 full tile rows + 16 valid rows in the last one; 200 tiles: one per workgroup
     g = torch.Generator(device="cpu").manual_seed(11)
     a = torch.randn(M, K, generator=g).to(dt).to(DEV)
