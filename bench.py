@@ -69,6 +69,8 @@ def main():
                     help="full (default): the last residual block is computed for every token, as the reference does and as the algorithmic "
                          "FLOP count of the metric assumes.  class-token: the engine's own default outside this benchmark - only what "
                          "ln_post(x[:, 0]) consumes (same logits bit for bit, 6 %% fewer FLOPs executed); its rate is reported beside the headline")
+    ap.add_argument("--walk", default=None, choices=["default", "c_proj", "c_fc", "alternate"],
+                    help="A/B: row walk-order policy of the block kernels (hip/engine.py _Walk; default: the engine's own, c_proj)")
     ap.add_argument("--image-dtype", default="compute", choices=["compute", "fp32"],
                     help="dtype the synthetic images are resident in when the timed region starts: the tower's compute dtype (default; SURVEY 8d: "
                          "'cast to bf16/fp16 for cfgs 2-5') or fp32 (the engine's patch-extraction kernel then casts inside the step)")
@@ -131,6 +133,8 @@ def main():
         if args.split:
             eng.split_sizes = [int(v) for v in args.split.split(",")]
         eng.cls_last_block = args.last_block == "class-token"
+        if args.walk is not None:
+            eng.walk = args.walk
         return cc
 
     def measure(cc, steps, warmup, profile_every):

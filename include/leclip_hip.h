@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 7
+#define LECLIP_ABI_VERSION 8
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -39,6 +39,13 @@ typedef enum { LECLIP_MASK_NONE = 0, LECLIP_MASK_CAUSAL = 1 } leclip_mask;
 int leclip_abi_version(void);
 const char* leclip_strerror(int code);
 const char* leclip_last_error(void);
+/* Walk-order hint for the NEXT launches issued by the calling thread (thread-local; results never depend on it): 0 = tiles / (batch, head)
+ * pairs in ascending row order, 1 = descending, -1 = the library's default (GEMMs ascending, the many-heads attention kernel descending).
+ * A consumer that walks its rows in the order OPPOSITE to its producer's starts on the rows the producer wrote last - the part of a
+ * 100 - 300 MB activation the 256 MiB memory-side cache still holds (hip/engine.py alternates the hint from launch to launch through a
+ * residual block; profiles/r04_walk_order.txt).  The reference has no counterpart (its kernels are the vendor's, clip/model.py:213-228).
+ * Returns the previous hint. */
+int leclip_set_walk_order(int order);
 /* Name of the device kernel family a GEMM call with these arguments dispatches to (for profiles/tests). */
 const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_dtype ab_dtype);
 

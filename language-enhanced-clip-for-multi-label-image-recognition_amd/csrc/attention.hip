@@ -885,11 +885,7 @@ extern "C" int leclip_attention_prefix_fwd(const void* qkv, void* out, int64_t B
     a.qkv = qkv; a.out = out; a.T = T; a.heads = heads; a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.scale_log2e = scale * 1.4426950408889634f; a.causal = mask == LECLIP_MASK_CAUSAL;
     a.q_rows = q_rows == T ? 0 : q_rows;
-#ifdef LECLIP_ATTN_FORWARD_ORDER      // A/B builds: the round-3 walk order
-    a.reverse = 0;
-#else
-    a.reverse = 1;
-#endif
+    a.reverse = leclip_walk_order() != 0;      // default (-1) and 1: the last (batch, head) pairs first (the qkv GEMM in front of it walks ascending by default)
 #ifdef LECLIP_DIAG
     a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
 #endif

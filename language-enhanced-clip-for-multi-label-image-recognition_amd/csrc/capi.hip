@@ -26,6 +26,14 @@ extern "C" int leclip_abi_version(void) { return LECLIP_ABI_VERSION; }
 
 extern "C" const char* leclip_last_error(void) { return g_err; }
 
+thread_local int g_leclip_walk_order = -1;
+int leclip_walk_order() { return g_leclip_walk_order; }
+extern "C" int leclip_set_walk_order(int order) {
+    const int prev = g_leclip_walk_order;
+    g_leclip_walk_order = order < 0 ? -1 : (order ? 1 : 0);
+    return prev;
+}
+
 extern "C" const char* leclip_strerror(int code) {
     switch (code) {
         case LECLIP_OK: return "ok";

@@ -56,6 +56,7 @@ struct Gemm256Args {
     int64_t lda, ldw;
     EpiParams epi;
     int tiles_n, tiles_total;
+    int reverse;      // walk the tiles from the last to the first (leclip_set_walk_order; which rows a workgroup takes, never what it computes)
     int im_R, im_G;   // IM2COL kernels: A is an NCHW image batch [B][3][R][R] of 16-bit pixels, row m = patch (b, gy, gx) of a G x G grid of 16 x 16
                       // patches, k = c * 256 + ky * 16 + kx (Conv2d weight order, clip/model.py:247); 0 = A is a plain [M][lda] matrix
     int desync;   // start-up stagger between workgroups, in units of ~8k cycles per phase step (0 = off)
@@ -298,6 +299,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
 #endif
 
     auto tile_origin = [&](int v, int64_t& m0, int& n0) {
+        if (g.reverse) v = g.tiles_total - 1 - v;   // walk-order hint (leclip_set_walk_order): last tile rows first
         const int tile = xcd_remap256(v, g.tiles_total);
         const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
         m0 = (int64_t)tm * TM;
@@ -837,6 +839,7 @@ int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K,
     a.tiles_total = (int)(tiles_m * a.tiles_n);
     a.dbg = a.desync = a.no_xtile = a.strict_wait = 0;
     a.im_R = a.im_G = 0;
+    a.reverse = leclip_walk_order() == 1;
     a.stamps = nullptr;
 #ifdef LECLIP_DIAG
     static const int dbg = [] { const char* e = getenv("LECLIP_GEMM_DEBUG"); return e ? atoi(e) : 0; }();
@@ -873,6 +876,7 @@ int leclip_gemm256_launch_im2col(const void* image, const void* W, int64_t B, in
     a.tiles_total = (int)(tiles_m * a.tiles_n);
     a.dbg = a.desync = a.no_xtile = a.strict_wait = 0;
     a.im_R = R; a.im_G = G;
+    a.reverse = leclip_walk_order() == 1;
     a.stamps = nullptr;
 #ifdef LECLIP_DIAG
     a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};

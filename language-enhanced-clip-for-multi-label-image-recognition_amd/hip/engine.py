@@ -95,9 +95,38 @@ class _Workspace:
             self.cls_pair_index = (torch.arange(d // 64, device=device, dtype=torch.int64)[:, None] * rows + self.cls_index[None, :]).reshape(-1).contiguous()
 
 
+class _Walk:
+    """Walk-order policy through a residual block's launches (leclip_set_walk_order: which rows a kernel takes first, never what it
+    computes).  A consumer that walks its rows in the order opposite to its producer's starts on the rows written last, which the 256 MiB
+    memory-side cache still holds.  Measured on MI355X at B = 256 (profiles/r04_walk_order.txt): c_proj, which reads the 310 MB MLP hidden,
+    gains 4 % from it with the batch as ONE part (259 -> 249 us), but qkv loses as much when its producer walks descending, and with the
+    batch as two stream parts - the product schedule - no policy moves the step time (-0.6 .. +0.1 %).  Policies (A/B: bench.py --walk):
+    "default" (library order for every launch; the engine's choice), "c_proj", "c_fc" (that kernel descending), "alternate"."""
+    ORDER = {"default": {}, "c_proj": {"c_proj": 1}, "c_fc": {"c_fc": 1},
+             "alternate": None}
+
+    def __init__(self, policy: str):
+        self.table = self.ORDER[policy]
+        self.on = policy != "default"
+        self.flip = 1
+
+    def set(self, kernel: str):
+        if not self.on:
+            return
+        if self.table is None:
+            ops.set_walk_order(self.flip)
+            self.flip ^= 1
+        else:
+            ops.set_walk_order(self.table.get(kernel, -1))
+
+    def done(self):
+        if self.on:
+            ops.set_walk_order(-1)
+
+
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
                taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, have_partials: bool = False,
-               cls_last: bool = False) -> torch.Tensor:
+               cls_last: bool = False, walk: str = "default") -> torch.Tensor:
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
@@ -125,8 +154,10 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
             src = dict(ln_stats=ws.stats)
         after = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
         last = len(blocks) - 1
+        walk = _Walk(walk)
         for i, p in enumerate(blocks):
             if cls_last and i == last:
+                walk.done()
                 x_c = x.view(batch, tokens * d)[:, :d]             # class rows in place: [B, d] with row stride T*d
                 cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
                 if "ln_partials" in src:
@@ -142,15 +173,21 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
                 ops.gemm_ln(ws.cls_x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.cls_u, **cls)
                 ops.gemm(ws.cls_u, p.w_pr, p.b_pr, residual=ws.cls_x, out=ws.cls_x)
                 return ws.cls_x
+            walk.set("qkv")
             ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
+            walk.set("attention")
             ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
+            walk.set("out_proj")
             ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
+            walk.set("c_fc")
             ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
+            walk.set("c_proj")
             if i < last:
                 ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
                 src = after
             else:
                 ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
+        walk.done()
         return x
     for i, p in enumerate(blocks):
         ops.layernorm(x, p.ln1_w, p.ln1_b, out=ws.h)
@@ -283,6 +320,9 @@ class VisionEngine:
         self.cls_last_block = True
         self.split_min_batch = 128        # from here on two parts always paid; below, only when the tile rounds are badly filled
         self.split_sizes = None           # experiments: explicit part sizes instead of an even split
+        # walk-order policy of the block kernels (run_blocks, _Walk): which rows a kernel takes first - same bits either way.  "default":
+        # with the batch as two stream parts (the product schedule) no policy measured a gain (profiles/r04_walk_order.txt)
+        self.walk = "default"
 
     def _parts(self, image: torch.Tensor):
         """Row ranges of the stream parts, or None when the batch runs as one piece."""
@@ -360,7 +400,8 @@ class VisionEngine:
                 taps["ln_pre"] = x.float().clone()
         cls_last = (cls_only and self.cls_last_block and taps is None and self.dtype != torch.float32 and self.width % 64 == 0
                     and self.width <= 1024 and self.proj.shape[1] % 16 == 0)     # (the conditions of the fused path and of the tail kernel)
-        rows = run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials, cls_last=cls_last)
+        rows = run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials, cls_last=cls_last,
+                          walk=self.walk)
         if cls_last:
             return rows, batch, None, self.width
         return x, batch, cls_rows, self.tokens * self.width

@@ -45,6 +45,12 @@ class _Timed:
         return False
 
 
+def set_walk_order(order: int) -> int:
+    """Walk-order hint for the calling thread's next launches (leclip_set_walk_order): 0 ascending rows, 1 descending, -1 library default.
+    Which rows a workgroup takes first, never what it computes.  Returns the previous hint."""
+    return _capi.load().leclip_set_walk_order(int(order))
+
+
 def dtype_code(dt: torch.dtype) -> int:
     try:
         return _DT[dt]
