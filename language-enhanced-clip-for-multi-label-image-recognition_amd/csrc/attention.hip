@@ -415,114 +415,6 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 #endif
 }
 
-// ---------------------------------------------------------------- three-buffer kernel for many heads, 192 < T <= 200 (ViT-B/16: T = 197)
-// Round 4.  attn_heads_kernel above keeps ONE head of K / V / Q in flight while it computes the head before it: a head's loads get exactly
-// one head of compute to land, the waves spend 42 % of their cycles parked at that wait and the barrier behind it (SQ_WAIT_ANY,
-// profiles/r03_pmc_summary.json), and the kernel moves 4.0 TB/s.  Here K and V of head i + 2 are requested while head i is computed
-// (bytes in flight per CU: 75 KB -> 125 KB), so a piece has two heads of compute to land:
-//   * three K and three V images of the 200 rows that exist (6 x 25 600 B = 150 KiB; the 224-row images of the two-buffer kernel allow two).
-//     A key tile reads 32 rows, so the last tile of an image reads 24 rows past it - the first rows of the NEXT image (or, behind the last
-//     one, 3 KiB of slack): finite numbers, and the scores of keys >= T are masked to an exact zero probability before they meet them.  LDS
-//     is zero-filled once so that this also holds before those neighbours have been written for the first time;
-//   * no room is left for the Q images of the two-buffer kernel: the wave's next Q block (16 VGPRs) is requested by INLINE-ASM loads at
-//     the top of a head and released by the counted wait at its end, which names the registers (tracked loads would make hipcc put
-//     s_waitcnt vmcnt(0) in front of their first use and drain the pieces that are to stay in flight; round 3's attempt at this kernel left
-//     such loads pending without tying them to a wait and faulted - profiles/r03_attention_lazy.txt 4a).  Nothing between issue and wait may
-//     touch those registers: tests/isa_audit.py checks the shipped code object for it;
-//   * waves 0 .. 6 own the 7 query blocks and move 6 pieces of a head each, wave 7 (no query block) the other 8: every wave's operation
-//     count per head is fixed, the waits are counted, one barrier per head.
-template <typename T>
-__global__ __launch_bounds__(512, 2) void attn_heads3_kernel(AttnArgs a, int total_heads) {
-    typedef typename VecOf<T>::v8 v8;
-    constexpr int NKT = 7, ROWS = 200, BUF = ROWS * 128, NP = ROWS / 8;     // NP = 25 pieces (8 rows x 128 B) per K or V image
-    constexpr int LDS_USED = 6 * BUF + 24 * 128;
-    extern __shared__ __attribute__((aligned(16))) char smem[];             // K[3][BUF] | V[3][BUF] | 3 KiB slack
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int d_model = a.heads * 64;
-    const int last = total_heads - 1;
-    auto eff = [&](int hd) { return a.reverse ? total_heads - 1 - hd : hd; };
-    auto head_base = [&](int hd) {
-        hd = eff(hd < last ? hd : last);            // past the end: a harmless re-load keeps the operation counts uniform
-        const int b = hd / a.heads, h = hd - b * a.heads;
-        return (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
-    };
-    // piece p of a head: 0 .. 24 = K, 25 .. 49 = V; source-side swizzles as in attn_heads_kernel; rows past T re-read row T - 1
-    auto piece = [&](const T* base, int buf, int p) {
-        const int isv = p >= NP ? 1 : 0;
-        const int pc = p - isv * NP;
-        const int row = pc * 8 + (lane >> 3);
-        const int q = lane & 7;
-        const int c = isv ? (q ^ (((row >> 1) & 1) << 2)) : (q ^ ((row >> 1) & 7));
-        const int grow = row < a.T ? row : a.T - 1;
-        const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + c * 8;
-        __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(smem + (isv * 3 + buf) * BUF + pc * 1024), 16, 0, 0);
-    };
-    auto issue6 = [&](const T* base, int buf) {     // waves 0 .. 6: pieces w, w + 7, ..., w + 35
-#pragma unroll
-        for (int u = 0; u < 6; ++u) piece(base, buf, wave + 7 * u);
-    };
-    auto issue8 = [&](const T* base, int buf) {     // wave 7: pieces 42 .. 49
-#pragma unroll
-        for (int u = 0; u < 8; ++u) piece(base, buf, 42 + u);
-    };
-    // Q fragments of the wave's 32-query block (MFMA B operand: lane (r = lane & 31, h = lane >> 5) holds Q[32 w + r][16 s + 8 h + j])
-    attn_i32x4 qn[4];
-    auto load_q = [&](const T* base) {
-        const int qi = wave * 32 + (lane & 31);
-        const int qrow = qi < a.T ? qi : a.T - 1;
-        const T* qp = base + (int64_t)qrow * a.ld_qkv + (lane >> 5) * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(qn[s]) : "v"(qp), "n"(s * 32) : "memory");
-    };
-#define Q_WAIT(n) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(qn[0]), "+v"(qn[1]), "+v"(qn[2]), "+v"(qn[3]) : "n"(n) : "memory")
-
-    for (int i = tid; i < LDS_USED / 16; i += 512) *(attn_i32x4*)(smem + i * 16) = attn_i32x4{0, 0, 0, 0};
-    __syncthreads();
-
-    int hd = blockIdx.x;
-    const bool active = wave < 7;                   // (192 < T <= 200: seven query blocks)
-    const int grid = gridDim.x;
-    if (active) {
-        load_q(head_base(hd));
-        issue6(head_base(hd), 0);
-        issue6(head_base(hd + grid), 1);
-        Q_WAIT(6);                                  // all but the second head's 6 pieces: Q and this wave's share of the first head are in
-    } else {
-        issue8(head_base(hd), 0);
-        issue8(head_base(hd + grid), 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    }
-    int cur = 0;
-    for (; hd < total_heads; hd += grid) {
-        // One barrier per head: every wave has (a) finished the head before this one, whose images are the ones refilled below, and (b)
-        // passed the counted wait of its previous iteration, so every share of head `hd` sits in images `cur`.
-        __builtin_amdgcn_s_barrier();
-        const int nb = cur == 0 ? 2 : cur - 1;      // (cur + 2) % 3
-        const T* b1 = head_base(hd + grid);
-        const T* b2 = head_base(hd + 2 * grid);
-        if (active) {
-            v8 q[4];
-#pragma unroll
-            for (int s = 0; s < 4; ++s) q[s] = __builtin_bit_cast(v8, qn[s]);
-            load_q(b1);
-            issue6(b2, nb);
-            const int he = eff(hd);
-            const int b = he / a.heads, h = he - b * a.heads;
-            T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
-            attn_qblock<T, NKT, true>(a, smem + cur * BUF, smem + (3 + cur) * BUF, q, obase, wave, lane);
-            // everything older than the 6 pieces of head hd + 2 and this head's 4 output stores has completed: the next Q block, this wave's
-            // share of head hd + 1 (requested a whole head ago) - without draining the stores just issued
-            Q_WAIT(10);
-        } else {
-            issue8(b2, nb);
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        }
-        cur = cur == 2 ? 0 : cur + 1;
-    }
-#undef Q_WAIT
-}
-
 // ---------------------------------------------------------------- streaming kernel for long sequences (ViT-L/14@336: T = 577)
 // One 512-thread workgroup per (batch, head); the head's whole K and V (T <= 640: 2 x 80 KiB) sit in LDS, each wave owns 32-query
 // blocks and walks the keys in chunks of 4 tiles (128 keys) with the online-softmax recurrence: the running row maximum m lives in
@@ -940,15 +832,6 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
     const bool pipe_ok = a.T > 192 && a.T <= 224;   // 7 query blocks for 8 waves
     if (pipe_ok && a.q_rows == 0 && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
         const int n_cu = leclip_cu_count();
-#ifndef LECLIP_ATTN_TWO_BUFFERS      // (A/B builds: the round-3 kernel for every T)
-        if (a.T <= 200 && grid >= 3u * (unsigned)n_cu) {      // three-buffer kernel: K / V two heads ahead (at least three heads per workgroup)
-            static bool attr_set3[LECLIP_MAX_DEVICES] = {};
-            constexpr int LDSB3 = 6 * 200 * 128 + 24 * 128;
-            leclip_set_max_lds(attn_heads3_kernel<T>, LDSB3, attr_set3);
-            hipLaunchKernelGGL((attn_heads3_kernel<T>), dim3((unsigned)n_cu), dim3(512), LDSB3, s, a, (int)grid);
-            return leclip_check_launch("attn_heads3_kernel");
-        }
-#endif
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
         constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
         leclip_set_max_lds(attn_heads_kernel<T, 7>, LDSB, attr_set);
