@@ -599,6 +599,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             typedef typename VecOf<T>::v4 v4t;
             typedef typename VecOf<T>::v8 v8t;
             drain = true;
+
             if (!(DIAG(g.dbg) & 1)) {
                 constexpr int PITCH = 136, STRIP = 16 * PITCH;
                 char* st = smem + STAGE_BYTES + 2 * SLOT_BYTES + wave * (2 * EPI_WAVE_BYTES);
