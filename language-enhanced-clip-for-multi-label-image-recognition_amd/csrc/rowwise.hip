@@ -147,6 +147,87 @@ __global__ __launch_bounds__(256) void embed_ln_pre_kernel(const TI* __restrict_
     }
 }
 
+// The same pass for the hot configuration (round 4): 16-bit conv output and stream of one type T, dim a multiple of 256.  A HALF-wave per row: lane l
+// of the half moves the 16-byte chunks l, l + 32, l + 64 .. of the row (the one-wave-per-row form above moves 8 bytes per lane and load: half the bytes per
+// memory instruction; 65 us at B = 256 against the 31 us its 154 MB take at 5 TB/s), 8 rows per 256-thread workgroup.  A 64-column block is the 8 consecutive
+// lanes of one load index, so the block partials are 8-lane butterflies; the row statistics 32-lane ones.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void embed_ln_pre16_kernel(const T* __restrict__ conv_out, const float* __restrict__ cls, const float* __restrict__ pos,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, T* __restrict__ y,
+                                                             float* __restrict__ stats_out, int64_t rows, int Tk, float eps) {
+    typedef typename VecOf<T>::v8 v8;
+    constexpr int dim = NV * 256;
+    const int l = threadIdx.x & 31;
+    const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;                     // (a half-wave leaves together; the butterflies below stay inside a half)
+    const int64_t b = row / Tk;
+    const int t = (int)(row - b * Tk);
+    const T* xr = conv_out + (b * (Tk - 1) + (t > 0 ? t - 1 : 0)) * dim;
+    const float* pr = pos + (int64_t)t * dim;
+    float v[NV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = j * 256 + l * 8;
+        const f32x4 p0 = *(const f32x4*)(pr + c), p1 = *(const f32x4*)(pr + c + 4);
+        if (t > 0) {
+            const v8 a8 = *(const v8*)(xr + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = (float)a8[e] + p0[e]; v[j][4 + e] = (float)a8[4 + e] + p1[e]; }
+        } else {
+            const f32x4 c0 = *(const f32x4*)(cls + c), c1 = *(const f32x4*)(cls + c + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[j][e] = c0[e] + p0[e]; v[j][4 + e] = c1[e] + p1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) s += v[j][e] + v[j][e + 1];
+    }
+#pragma unroll
+    for (int of = 1; of < 32; of <<= 1) s += __shfl_xor(s, of);
+    const float mean = s * (1.0f / (float)dim);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[j][e] - mean; q = fmaf(d, d, q); }
+#pragma unroll
+    for (int of = 1; of < 32; of <<= 1) q += __shfl_xor(q, of);
+    const float rstd = rsqrtf(q * (1.0f / (float)dim) + eps);
+    T* yr = y + row * dim;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = j * 256 + l * 8;
+        const f32x4 g0 = *(const f32x4*)(gamma + c), g1 = *(const f32x4*)(gamma + c + 4);
+        const f32x4 b0 = *(const f32x4*)(beta + c), b1 = *(const f32x4*)(beta + c + 4);
+        v8 o8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o8[e] = (T)((v[j][e] - mean) * rstd * g0[e] + b0[e]);
+            o8[4 + e] = (T)((v[j][4 + e] - mean) * rstd * g1[e] + b1[e]);
+        }
+        *(v8*)(yr + c) = o8;
+        if (stats_out) {
+            // (sum, M2 about the block mean) of the STORED values of the 64-column block j * 4 + (l >> 3): the quantities a GEMM epilogue emits
+            float s1 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s1 += (float)o8[e];
+#pragma unroll
+            for (int of = 1; of < 8; of <<= 1) s1 += __shfl_xor(s1, of);
+            const float mb = s1 * (1.0f / 64.0f);
+            float m2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float dl = (float)o8[e] - mb; m2 = fmaf(dl, dl, m2); }
+#pragma unroll
+            for (int of = 1; of < 8; of <<= 1) m2 += __shfl_xor(m2, of);
+            if ((l & 7) == 0) {
+                f32x2 w;
+                w[0] = s1; w[1] = m2;
+                *(f32x2*)(stats_out + ((int64_t)(j * 4 + (l >> 3)) * rows + row) * 2) = w;     // slot-major [dim/64][rows][2]
+            }
+        }
+    }
+}
+
 template <typename TI>
 int ln_dispatch_out(const void* x, const float* g, const float* b, void* y, int64_t rows, int dim, int64_t ldx,
                     int64_t ldy, float eps, int ydt, hipStream_t s) {
@@ -664,6 +745,15 @@ extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, cons
     rc = direct ? leclip_gemm256_launch_im2col(image, Wp, B, R, width, Kp, e, (int)w_dtype, s)
                 : leclip_gemm_dispatch(workspace, Wp, n_rows, width, Kp, Kp, Kp, e, w_dtype, s);
     if (rc) return rc;
+    if (w_dtype != LECLIP_F32 && x_dtype == w_dtype && width % 256 == 0 && width <= 1024) {      // the hot configuration: half a wave per row, 16-byte accesses
+        const dim3 grid8((unsigned)((B * T + 7) / 8)), block8(256);
+#define LAUNCH_EMB16(TT, NV) hipLaunchKernelGGL((embed_ln_pre16_kernel<TT, NV>), grid8, block8, 0, s, (const TT*)conv, class_emb, pos, gamma, beta, (TT*)X, stats_out, B * T, T, eps)
+#define LAUNCH_EMB16_T(TT) do { if (width == 256) LAUNCH_EMB16(TT, 1); else if (width == 512) LAUNCH_EMB16(TT, 2); else if (width == 768) LAUNCH_EMB16(TT, 3); else LAUNCH_EMB16(TT, 4); } while (0)
+        if (w_dtype == LECLIP_F16) LAUNCH_EMB16_T(f16_t); else LAUNCH_EMB16_T(bf16_t);
+#undef LAUNCH_EMB16_T
+#undef LAUNCH_EMB16
+        return leclip_check_launch("embed_ln_pre16_kernel");
+    }
     const dim3 grid((unsigned)((B * T + 3) / 4)), block(256);
 #define LAUNCH_EMB(TI, TO) hipLaunchKernelGGL((embed_ln_pre_kernel<TI, TO>), grid, block, 0, s, (const TI*)conv, class_emb, pos, gamma, beta, (TO*)X, stats_out, B * T, T, width, eps)
     if (w_dtype == LECLIP_F32) { if (x_dtype != LECLIP_F32) { leclip_set_error("patch_embed_ln: fp32 weights need an fp32 stream"); return LECLIP_E_UNSUPPORTED; } LAUNCH_EMB(float, float); }
