@@ -1,15 +1,17 @@
 #!/bin/bash
-# Runs ON THE GPU BOX (via gpurun):  bash profiles/collect.sh r03
+# Runs ON THE GPU BOX (via gpurun):  bash profiles/collect.sh r04 main   then   bash profiles/collect.sh r04 extra   (one call each: a call is limited to 20 minutes)
 # kernel-trace stats + separate PMC passes (never combined with other trace domains) for the benchmark command, the
 # ViT-L/14@336 large-model point (BASELINE configs[4], one GPU's share B=128) and the prompt-tuning step (configs[2]).
 # Raw output under gpurun_out/prof_<tag>/ ; `python profiles/summarize.py <tag>` turns it into the committed files.
 set -o pipefail
-TAG=${1:-r03}
+TAG=${1:-r04}
+PART=${2:-all}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp
+if [ "$PART" = all ] || [ "$PART" = main ]; then
 # --streams 1: each kernel has the chip to itself, as on the sampled steps bench.py takes its roofline block from (in the default
 # two-part mode a dispatch's begin..end spans the time it shares the CUs with the other stream's kernel); the two-part trace
 # follows as trace2 for the record.
@@ -24,6 +26,13 @@ echo pmc mem done
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT/pmc_sq.log 2>&1 || exit 1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1 || exit 1
 echo pmc sq done
+cd $R
+timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+echo main collected
+if [ "$PART" = main ]; then exit 0; fi
+fi
+if [ "$PART" = all ] || [ "$PART" = extra ]; then
+cd /tmp
 # ViT-L/14@336 (BASELINE configs[4], one GPU's share): --streams 1 so that a dispatch's duration is the kernel alone on the chip (the
 # round-2 trace was taken in two-part mode, where a small kernel's begin..end includes queueing behind the other part's persistent grid:
 # ln_stats_finalize_kernel read 112 us there)
@@ -42,5 +51,5 @@ cd $R
 timeout -k 10 300 python3 bench.py --mode tune --tune-model DenseCLIP --dtype fp16 --steps 10 --warmup 3 > $OUT/tune_dense_bench.json 2> $OUT/tune_dense_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --arch ViT-L/14@336px --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --no-second-dtype > $OUT/vitl_bench.json 2> $OUT/vitl_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --mode tune --dtype bf16 --steps 10 --warmup 3 > $OUT/tune_bench.json 2> $OUT/tune_bench.err || exit 1
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
-echo collected
+echo extra collected
+fi

@@ -3,7 +3,7 @@
 <tag>_kernel_stats.csv, <tag>_pmc_summary.json, <tag>_vitl_kernel_stats.csv, <tag>_tune_kernel_stats.csv and the bench JSON lines.
     python profiles/summarize.py r02"""
 import collections, csv, glob, json, os, shutil, sys
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
@@ -65,10 +65,17 @@ out[GEMM] = {"dispatches_averaged": nf, "FETCH_SIZE_KB": fetch.get("FETCH_SIZE")
              "SQ": sq, "GRBM_GUI_ACTIVE": grbm.get("GRBM_GUI_ACTIVE"),
              "mfma_busy_frac_of_simd_cycles": sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(grbm.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)}
 out["gemm_hbm_bytes_per_launch"] = rd + wr
-for name in ("attn_heads_kernel", "gemm_tn_128x128x64", "image_tail_kernel", "embed_ln_pre_kernel"):
+for name in ("attn_heads_kernel", "gemm_tn_128x128x64", "image_tail_kernel", "embed_ln_pre"):
     f2, _ = by_kernel(counters("pmc_fetch"), name)
     w2, _ = by_kernel(counters("pmc_write"), name)
     out[name] = {"read_bytes_corrected": 2 * f2.get("FETCH_SIZE", 0) * 1024, "write_bytes": w2.get("WRITE_SIZE", 0) * 1024}
+# round 4: the im2col-free patch GEMM (IM2COL flavour <T,0,0,true>) on its own; with embed_ln_pre above it is the whole patch path
+f3, _ = by_kernel(counters("pmc_fetch"), GEMM + "IDF16_Li0ELi0ELb1")
+w3, _ = by_kernel(counters("pmc_write"), GEMM + "IDF16_Li0ELi0ELb1")
+out["patch GEMM (im2col-free)"] = {"read_bytes_corrected": 2 * f3.get("FETCH_SIZE", 0) * 1024, "write_bytes": w3.get("WRITE_SIZE", 0) * 1024}
+pp = out["patch GEMM (im2col-free)"]["read_bytes_corrected"] + out["patch GEMM (im2col-free)"]["write_bytes"] + out["embed_ln_pre"]["read_bytes_corrected"] + out["embed_ln_pre"]["write_bytes"]
+out["patch_path_bytes"] = {"measured": pp, "algorithmic_fp16_image": 256 * 3 * 224 * 224 * 2 + 256 * 197 * 768 * 2 + 768 * 768 * 2,
+                           "note": "image in the compute dtype (77 MB) + tokens out (77.5 MB) + weights; the conv output makes one round trip between the two launches"}
 # attention: SQ counters of the ViT-B heads kernel (same passes as the GEMM) and of the ViT-L/14@336 stream kernel (its own passes)
 sq_h, _ = by_kernel(counters("pmc_sq"), "attn_heads_kernel")
 g_h, _ = by_kernel(counters("pmc_grbm"), "attn_heads_kernel")

@@ -494,10 +494,10 @@ def test_vitb16_cfg1_golden(ops, golden_dir, dt, dist):
         assert np.array_equal(lpi.argmax(1)[ok], ref.argmax(1)[ok])
 
 
-# constant label-index bands (VERDICT r3 weak 2 / task 7): two oracle logits closer than the band cannot be ordered by arithmetic with that
-# error, a disagreement outside it is a wrong result.  Derived once from the measured maximum logit error at scale 4.0 (fp16 2.5e-3 - 3.1e-3,
-# bf16 2.8e-2 - 3.3e-2 over rounds 2 - 4), doubled for the two logits involved; a uniformly worse kernel no longer widens its own band.
-LABEL_BAND = {torch.float32: 1e-4, torch.float16: 6e-3, torch.bfloat16: 6e-2}
+# constant label-index bands (VERDICT r3 weak 2 / task 7) = the a-priori logit tolerances of this file at scale 4.0 (fp32: the north star's 1e-3; fp16 4e-3,
+# bf16 4e-2; measured maxima over rounds 2 - 4: 5e-6, 2.5e-3 .. 3.2e-3, 2.8e-2 .. 3.3e-2): two reference logits closer than the band cannot be ordered by
+# arithmetic with that error, a disagreement outside it is a wrong result; a uniformly worse kernel cannot widen its own band (bench.py uses the same numbers).
+LABEL_BAND = {torch.float32: 1e-3, torch.float16: 4e-3, torch.bfloat16: 4e-2}
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -1154,6 +1154,16 @@ def test_bench_self_launches_two_ranks_on_one_gpu():
     assert d["config"]["global_batch"] == 64 and "allgather" in d["config"]["parallelism"] and d["value"] > 0
     assert "LECLIP_DIST_BACKEND=gloo" in d["env_overrides"]
     assert abs(d["value"] - 64 * 3 / (d["ms_per_step"] * 1e-3 * 3)) / d["value"] < 1e-6
+    assert d["config"]["world_size"] == 2 and d["config"]["backend"] == "gloo" and "mAP_gathered" not in d     # (B = 32: not the fixture's workload)
+    # BASELINE configs[3]'s "eval mAP" on the all-gathered logits, at the benchmark's own batch: two ranks x 256 images, scored by rank 0 against
+    # the committed reference logits of exactly those 512 images (tests/golden/vitb16_cfg4_logits.npz) - no CPU oracle in the loop
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline", "--no-second-dtype", "--profile-every", "0"], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][0])
+    m = d["mAP_gathered"]
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 512 and m["n_images"] == 512
+    assert abs(m["delta"]) <= 0.2 and m["accuracy_gate"].startswith("met") and m["max_abs_logit_diff"] <= 4e-3 and m["top1_agree"] >= 0.98
 
 
 def test_caption_feature_mixing_kernel(ops, golden_dir):
