@@ -829,7 +829,11 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
 #else
     constexpr int force_pipe = -1;
 #endif
+#ifdef LECLIP_ATTN_NO_PIPE     // A/B builds: every T <= 224 call on attn_rows_kernel (one 256-thread workgroup per (batch, head), two resident per CU)
+    const bool pipe_ok = false;
+#else
     const bool pipe_ok = a.T > 192 && a.T <= 224;   // 7 query blocks for 8 waves
+#endif
     if (pipe_ok && a.q_rows == 0 && (force_pipe == 1 || (force_pipe != 0 && grid >= 1024))) {   // enough heads to keep every CU busy
         const int n_cu = leclip_cu_count();
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
