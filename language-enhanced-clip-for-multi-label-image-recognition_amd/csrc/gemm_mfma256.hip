@@ -639,12 +639,25 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
                     for (int j = 0; j < 4; ++j) {
                         v4t w;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float v = p.acc[q >> 2][q & 3][j][r];
-                            if constexpr (PF == 2) v = fmaf(rstd, fmaf(-mean, s16[4 * j + r], v), b16[4 * j + r]);
-                            else v += b16[4 * j + r];
-                            if constexpr (ACT == 1) v = v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-2.4554669595930157f * v));
-                            w[r] = (T)v;
+                        for (int r = 0; r < 4; r += 2) {
+                            // two columns at a time as a float pair: the multiply, the 1 + e and the final product issue as
+                            // packed fp32 instructions (same IEEE operations, half the issue slots); exp2 / rcp stay per element
+                            typedef float f2 __attribute__((ext_vector_type(2)));
+                            f2 v = {p.acc[q >> 2][q & 3][j][r], p.acc[q >> 2][q & 3][j][r + 1]};
+                            const f2 bb = {b16[4 * j + r], b16[4 * j + r + 1]};
+                            if constexpr (PF == 2) {
+                                const f2 ss = {s16[4 * j + r], s16[4 * j + r + 1]};
+                                v = __builtin_elementwise_fma((f2)(rstd), __builtin_elementwise_fma((f2)(-mean), ss, v), bb);
+                            } else v += bb;
+                            if constexpr (ACT == 1) {
+                                const f2 t = v * (f2)(-2.4554669595930157f);
+                                f2 d = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+                                d += (f2)(1.0f);
+                                const f2 rc = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+                                v *= rc;
+                            }
+                            w[r] = (T)v.x;
+                            w[r + 1] = (T)v.y;
                         }
                         *(v4t*)(sq + j * 32) = w;
                     }
