@@ -171,18 +171,25 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
         }
         mx = lane32_max(mx);   // the query's other lane (v_permlane32_swap: no LDS round trip)
-        float sum = 0.f;
         const float mb = mx * a.scale_log2e;
+        // Two keys at a time as a float pair: the scale-and-shift and the row sum issue as packed fp32 instructions (v_pk_fma_f32 /
+        // v_pk_add_f32: half the issue slots of that half of the softmax; the sum runs as an even-key and an odd-key partial).
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        f2 sum2 = {0.f, 0.f};
+        const f2 scl2 = (f2)(a.scale_log2e), nmb2 = (f2)(-mb);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 // v_exp_f32 directly: arguments are <= 0, results below 2^-126 flush to 0 (masked keys: exactly 0)
-                const float p = __builtin_amdgcn_exp2f(fmaf(sc[kt][r], a.scale_log2e, -mb));
-                sc[kt][r] = p;
-                sum += p;
+                f2 x = {sc[kt][r], sc[kt][r + 1]};
+                x = __builtin_elementwise_fma(x, scl2, nmb2);
+                const f2 p = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+                sc[kt][r] = p.x;
+                sc[kt][r + 1] = p.y;
+                sum2 += p;
             }
-        sum = lane32_sum(sum);
+        const float sum = lane32_sum(sum2.x + sum2.y);
         const float inv = 1.0f / sum;
 
         // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
