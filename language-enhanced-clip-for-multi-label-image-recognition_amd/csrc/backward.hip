@@ -216,6 +216,247 @@ __global__ __launch_bounds__(AB_THREADS) void attn_bwd_kernel(const T* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------- attention backward, matrix cores (16-bit dtypes)
+// The same mathematics as attn_bwd_kernel, T <= 96, for f16 / bf16 operands: the five T x T x 64 contractions run on v_mfma_f32_32x32x16 with fp32
+// accumulation, probabilities and score gradients never touch memory.  One 256-thread workgroup per (batch, head); Q, K, V, dO of the head sit in LDS
+// as 16-bit row images (96 rows x 144 B: the 16-byte pad keeps the 16-byte fragment reads of 32 consecutive rows off each other's banks; rows past T are zero).
+// Both operand patterns of the forward kernel (attention.hip) are reused, each in BOTH orientations, so that a contraction index always lies inside a lane's
+// accumulator registers and P / dS go from accumulators straight into the next MFMA's B operand:
+//   pass A, wave = 32-query block:  S^T = K Q^T and dP^T = V dO^T (keys on accumulator rows, the query on the lane: row maximum, row sum and
+//           D[q] = sum_k P[q][k] dP[q][k] (= dO[q] . O[q]) need one lane exchange);  dS^T = scale P^T o (dP^T - D);  dQ^T = K^T dS^T with K^T fragments from the
+//           transposing LDS read (ds_read_b64_tr_b16), as the forward's O^T = V^T P^T.  The block's (maximum, sum, D) go to LDS.
+//   pass B, wave = 32-key block:    S = Q K^T and dP = dO V^T (queries on accumulator rows, the key on the lane), P and dS rebuilt with the published row
+//           statistics;  dV^T = dO^T P,  dK^T = Q^T dS  (dO^T, Q^T by transposing reads).
+// P and dS are rounded to the operand type where they enter an MFMA (as the forward rounds P); everything else is fp32.
+constexpr int ABM_PB = 144, ABM_ROWS = 96, ABM_IMG = ABM_ROWS * ABM_PB;
+constexpr int ABM_LDS = 4 * ABM_IMG + 3 * ABM_ROWS * 4;
+
+__device__ __forceinline__ float bw_lane32_max(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float bw_lane32_sum(float v) {
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+// lane (c = lane & 31, h = lane >> 5) holds X^T[32 i + (r & 3) + 8 (r >> 2) + 4 h][c] in o[i][r]: row c of X, 64 columns, to global (16-byte stores after
+// the two lanes of a row exchanged halves - attention.hip attn_store_block)
+template <typename T>
+__device__ __forceinline__ void bw_store_rows(const f32x16 (&o)[2], T* op, int fh, bool on) {
+    typedef typename VecOf<T>::v4 v4;
+    typedef __attribute__((ext_vector_type(2))) unsigned u32x2;
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            v4 wa, wb;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wa[e] = (T)o[i][8 * k + e]; wb[e] = (T)o[i][8 * k + 4 + e]; }
+            const u32x2 a2 = __builtin_bit_cast(u32x2, wa), b2 = __builtin_bit_cast(u32x2, wb);
+            const u32x2 s0 = __builtin_amdgcn_permlane32_swap(a2[0], b2[0], false, false);
+            const u32x2 s1 = __builtin_amdgcn_permlane32_swap(a2[1], b2[1], false, false);
+            i32x4 w;
+            w[0] = (int)s0[0]; w[1] = (int)s1[0]; w[2] = (int)s0[1]; w[3] = (int)s1[1];
+            if (on) *(i32x4*)(op + 32 * i + 16 * k + 8 * fh) = w;
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_bwd_mfma_kernel(const T* __restrict__ qkv, const T* __restrict__ dout, T* __restrict__ dqkv,
+                                                               int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale, int causal) {
+    typedef typename VecOf<T>::v8 v8;
+    typedef typename VecOf<T>::v4 v4;
+    extern __shared__ __attribute__((aligned(16))) char smb[];
+    char* sQ = smb;
+    char* sK = sQ + ABM_IMG;
+    char* sV = sK + ABM_IMG;
+    char* sG = sV + ABM_IMG;                                  // dO
+    float* sM = (float*)(sG + ABM_IMG);                       // row maximum of scale * log2(e) * S
+    float* sL = sM + ABM_ROWS;                                // 1 / row sum of exp2
+    float* sD = sL + ABM_ROWS;                                // D[q]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int b = blockIdx.x / heads, h = blockIdx.x - b * heads;
+    const int d_model = heads * 64;
+    const T* base = qkv + (int64_t)b * Tn * ld_qkv + h * 64;
+    const T* dob = dout + (int64_t)b * Tn * ld_out + h * 64;
+    T* dqb = dqkv + (int64_t)b * Tn * ld_qkv + h * 64;
+    // ---- the head's four operands -> LDS images (16-byte chunks; rows past T zero)
+#pragma unroll
+    for (int it = 0; it < 12; ++it) {
+        const int idx = it * 256 + tid;
+        const int which = idx / (ABM_ROWS * 8), rem = idx - which * (ABM_ROWS * 8);
+        const int r = rem >> 3, c = rem & 7;
+        v8 val;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) val[j] = (T)0.f;
+        if (r < Tn) val = which < 3 ? *(const v8*)(base + (int64_t)r * ld_qkv + which * d_model + c * 8) : *(const v8*)(dob + (int64_t)r * ld_out + c * 8);
+        *(v8*)(smb + which * ABM_IMG + r * ABM_PB + c * 16) = val;
+    }
+    __syncthreads();
+    const int nb = (Tn + 31) >> 5;                            // 32-row blocks with live rows (<= 3)
+    const int fr = lane & 31, fh = lane >> 5, li = lane & 15, dgrp = (lane >> 4) & 1;
+    const float c2 = scale * 1.4426950408889634f;
+    const int frag_off = fr * ABM_PB + fh * 16;               // fragment row fr, 16-byte chunk 2 s + fh
+    const int tr_off = (4 * fh + (li >> 2)) * ABM_PB + 32 * dgrp + 8 * (li & 3);   // transposing read: row 4 fh + (li >> 2), 4 columns at 16 dgrp + 4 (li & 3)
+
+    // ---------------- pass A: this wave's 32 queries against every key
+    if (wave < nb) {
+        const int qi = wave * 32 + fr;
+        v8 qf[4], gf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qf[s] = *(const v8*)(sQ + wave * 32 * ABM_PB + frag_off + s * 32);
+            gf[s] = *(const v8*)(sG + wave * 32 * ABM_PB + frag_off + s * 32);
+        }
+        f32x16 sc[3], dp[3];
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[kt][r] = 0.f; dp[kt][r] = 0.f; }
+            if (kt < nb) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const v8 kf = *(const v8*)(sK + kt * 32 * ABM_PB + frag_off + s * 32);
+                    const v8 vf = *(const v8*)(sV + kt * 32 * ABM_PB + frag_off + s * 32);
+                    sc[kt] = mfma_32x32x16(kf, qf[s], sc[kt]);
+                    dp[kt] = mfma_32x32x16(vf, gf[s], dp[kt]);
+                }
+            }
+        }
+        // masked softmax over keys (this lane: keys kt*32 + (r & 3) + 8 (r >> 2) + 4 fh of query qi)
+        const int klimit = causal ? (qi < Tn - 1 ? qi : Tn - 1) : Tn - 1;
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                sc[kt][r] = key <= klimit ? sc[kt][r] * c2 : -3.0e38f;
+                mx = fmaxf(mx, sc[kt][r]);
+            }
+        mx = bw_lane32_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(sc[kt][r] - mx);   // masked: exp2(-huge) = 0
+                sc[kt][r] = pv;
+                sum += pv;
+            }
+        sum = bw_lane32_sum(sum);
+        const float inv = 1.0f / sum;
+        float dd = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sc[kt][r] *= inv; dd = fmaf(sc[kt][r], dp[kt][r], dd); }
+        dd = bw_lane32_sum(dd);
+        if (fh == 0) { sM[qi] = mx; sL[qi] = inv; sD[qi] = dd; }
+        // dS^T = scale P^T o (dP^T - D);  dQ^T = K^T dS^T
+        f32x16 o[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 3; ++kt) {
+            if (kt < nb) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    v8 pf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pf[j] = (T)(scale * sc[kt][8 * s2 + j] * (dp[kt][8 * s2 + j] - dd));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        v8 kt8;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const v4 t4 = lds_read_tr16((const T*)(sK + (kt * 32 + 16 * s2 + 8 * u) * ABM_PB + tr_off + 64 * i));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) kt8[4 * u + e] = t4[e];
+                        }
+                        o[i] = mfma_32x32x16(kt8, pf, o[i]);
+                    }
+                }
+            }
+        }
+        bw_store_rows<T>(o, dqb + (int64_t)(qi < Tn ? qi : 0) * ld_qkv, fh, qi < Tn);
+    }
+    __syncthreads();
+    // ---------------- pass B: this wave's 32 keys against every query
+    if (wave < nb) {
+        const int key = wave * 32 + fr;
+        v8 kf[4], vf[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            kf[s] = *(const v8*)(sK + wave * 32 * ABM_PB + frag_off + s * 32);
+            vf[s] = *(const v8*)(sV + wave * 32 * ABM_PB + frag_off + s * 32);
+        }
+        f32x16 ov[2], ok[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { ov[i][r] = 0.f; ok[i][r] = 0.f; }
+#pragma unroll
+        for (int qt = 0; qt < 3; ++qt) {
+            if (qt < nb) {
+                f32x16 sc, dp;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sc[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const v8 qa = *(const v8*)(sQ + qt * 32 * ABM_PB + frag_off + s * 32);
+                    const v8 ga = *(const v8*)(sG + qt * 32 * ABM_PB + frag_off + s * 32);
+                    sc = mfma_32x32x16(qa, kf[s], sc);
+                    dp = mfma_32x32x16(ga, vf[s], dp);
+                }
+                // this lane: queries qt*32 + (r & 3) + 8 (r >> 2) + 4 fh against key `key`
+                f32x16 ds;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int q0 = qt * 32 + 8 * g4 + 4 * fh;
+                    const f32x4 m4 = *(const f32x4*)(sM + q0), l4 = *(const f32x4*)(sL + q0), d4 = *(const f32x4*)(sD + q0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g4 + e, q = q0 + e;
+                        const bool valid = key < Tn && (!causal || key <= q);
+                        const float pv = valid ? __builtin_amdgcn_exp2f(sc[r] * c2 - m4[e]) * l4[e] : 0.f;
+                        sc[r] = pv;
+                        ds[r] = scale * pv * (dp[r] - d4[e]);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    v8 pf, sf;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { pf[j] = (T)sc[8 * s2 + j]; sf[j] = (T)ds[8 * s2 + j]; }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        v8 g8, q8;
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int off = (qt * 32 + 16 * s2 + 8 * u) * ABM_PB + tr_off + 64 * i;
+                            const v4 tg = lds_read_tr16((const T*)(sG + off)), tq = lds_read_tr16((const T*)(sQ + off));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { g8[4 * u + e] = tg[e]; q8[4 * u + e] = tq[e]; }
+                        }
+                        ov[i] = mfma_32x32x16(g8, pf, ov[i]);
+                        ok[i] = mfma_32x32x16(q8, sf, ok[i]);
+                    }
+                }
+            }
+        }
+        T* row = dqb + (int64_t)(key < Tn ? key : 0) * ld_qkv;
+        bw_store_rows<T>(ok, row + d_model, fh, key < Tn);
+        bw_store_rows<T>(ov, row + 2 * d_model, fh, key < Tn);
+    }
+}
+
 template <typename T>
 int ln_bwd_launch(const void* dy, const void* x, const float* gamma, const void* add, void* dx, int64_t rows, int dim, float eps, hipStream_t s) {
     hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, (const T*)dy, (const T*)x, gamma,
@@ -229,6 +470,15 @@ int gelu_launch(const void* pre, const void* du, void* out, int64_t n, bool bwd,
     if (bwd) hipLaunchKernelGGL((quickgelu_kernel<T, true>), grid, block, 0, s, (const T*)pre, (const T*)du, (T*)out, n4);
     else hipLaunchKernelGGL((quickgelu_kernel<T, false>), grid, block, 0, s, (const T*)pre, (const T*)du, (T*)out, n4);
     return leclip_check_launch("quickgelu_kernel");
+}
+template <typename T>
+int attn_bwd_mfma_launch(const void* qkv, const void* dout, void* dqkv, int64_t B, int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale,
+                         int causal, hipStream_t s) {
+    static bool attr_set[LECLIP_MAX_DEVICES] = {};
+    leclip_set_max_lds(attn_bwd_mfma_kernel<T>, ABM_LDS, attr_set);
+    hipLaunchKernelGGL((attn_bwd_mfma_kernel<T>), dim3((unsigned)(B * heads)), dim3(256), ABM_LDS, s, (const T*)qkv, (const T*)dout, (T*)dqkv, Tn, heads,
+                       ld_qkv, ld_out, scale, causal);
+    return leclip_check_launch("attn_bwd_mfma_kernel");
 }
 template <typename T>
 int attn_bwd_launch(const void* qkv, const void* dout, void* dqkv, int64_t B, int Tn, int heads, int64_t ld_qkv, int64_t ld_out, float scale,
@@ -282,6 +532,10 @@ extern "C" int leclip_attention_bwd(const void* qkv, const void* dout, void* dqk
     hipStream_t s = (hipStream_t)stream;
     const int causal = mask == LECLIP_MASK_CAUSAL;
     if (dtype == LECLIP_F32) return attn_bwd_launch<float>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s);
-    if (dtype == LECLIP_F16) return attn_bwd_launch<f16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s);
-    return attn_bwd_launch<bf16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s);
+    // 16-bit operands, T <= 96, 16-byte rows: the matrix-core kernel (fp32: the vector kernel, whose arithmetic is fp32 throughout)
+    const bool mfma_ok = T <= ABM_ROWS && ld_qkv % 8 == 0 && ld_out % 8 == 0;
+    if (dtype == LECLIP_F16) return mfma_ok ? attn_bwd_mfma_launch<f16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s)
+                                            : attn_bwd_launch<f16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s);
+    return mfma_ok ? attn_bwd_mfma_launch<bf16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s)
+                   : attn_bwd_launch<bf16_t>(qkv, dout, dqkv, B, T, heads, ld_qkv, ld_out, scale, causal, s);
 }

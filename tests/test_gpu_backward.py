@@ -58,7 +58,10 @@ def test_quickgelu_fwd_bwd(ops, dt):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("cfg", [(3, 77, 8, True), (2, 17, 2, False), (1, 100, 1, True)])
+# T <= 96 in 16 bits runs the matrix-core kernel (one, two and three 32-row blocks, a block boundary, a single row, the full 96), T = 100 and fp32 the
+# vector kernel
+@pytest.mark.parametrize("cfg", [(3, 77, 8, True), (2, 17, 2, False), (1, 100, 1, True), (2, 32, 2, True), (2, 33, 1, False), (1, 64, 2, True),
+                                 (2, 96, 2, True), (2, 96, 1, False), (1, 1, 1, False)])
 def test_attention_bwd(ops, dt, cfg):
     b, t, h, causal = cfg
     d = 64 * h
