@@ -17,6 +17,11 @@ struct GemmF32Args {
     int64_t lda, ldw;
     EpiParams epi;
     int tiles_n;
+    // split-K (few output tiles, long K: the prompt-feature gradients of the local head contract over every caption token): workgroup
+    // (tile, split) accumulates K-range [split * kchunk, ...) and writes its raw fp32 tile to partial[split][M][N]; gemm_f32_reduce adds the
+    // splits in index order (deterministic) and applies the epilogue.  partial == nullptr: one workgroup per tile, the whole K.
+    int tiles, splits, kchunk;
+    float* partial;
 };
 
 __global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
@@ -24,16 +29,19 @@ __global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
     __shared__ float Bs[FK * LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
-    const int tm = blockIdx.x / g.tiles_n, tn = blockIdx.x - tm * g.tiles_n;
+    const int split = blockIdx.x / g.tiles, tile = blockIdx.x - split * g.tiles;
+    const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
     const int64_t m0 = (int64_t)tm * FM;
     const int n0 = tn * FN;
+    const int k0 = split * g.kchunk;
+    const int klen = g.K - k0 < g.kchunk ? g.K - k0 : g.kchunk;
 
     // loader mapping: thread -> (row = tid>>2, 8 consecutive k at (tid&3)*8)
     const int lrow = tid >> 2, lk = (tid & 3) * 8;
     int64_t arow = m0 + lrow;
     arow = arow < g.M ? arow : g.M - 1;
-    const float* ap = g.A + arow * g.lda + lk;
-    const float* wp = g.W + (int64_t)(n0 + lrow) * g.ldw + lk;
+    const float* ap = g.A + arow * g.lda + k0 + lk;
+    const float* wp = g.W + (int64_t)(n0 + lrow) * g.ldw + k0 + lk;
 
     f32x16 acc;
 #pragma unroll
@@ -41,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
 
     f32x4 ra0 = *(const f32x4*)(ap), ra1 = *(const f32x4*)(ap + 4);
     f32x4 rb0 = *(const f32x4*)(wp), rb1 = *(const f32x4*)(wp + 4);
-    const int nk = g.K / FK;
+    const int nk = klen / FK;
     for (int t = 0; t < nk; ++t) {
         __syncthreads();
 #pragma unroll
@@ -68,6 +76,14 @@ __global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
 
     const EpiParams& e = g.epi;
     const int n = n0 + wc * 32 + (lane & 31);
+    if (g.partial) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m < g.M) g.partial[((int64_t)split * g.M + m) * g.N + n] = acc[r];
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int64_t m = m0 + wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -76,6 +92,16 @@ __global__ __launch_bounds__(256) void gemm_f32_64x64x32(GemmF32Args g) {
             store_elem(e.out, e.out_dt, epi_out_row(e, m) * e.ldy + n, v);
         }
     }
+}
+
+__global__ __launch_bounds__(256) void gemm_f32_reduce(GemmF32Args g) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= g.M * g.N) return;
+    const int64_t m = i / g.N;
+    const int n = (int)(i - m * g.N);
+    float v = 0.f;
+    for (int sp = 0; sp < g.splits; ++sp) v += g.partial[(int64_t)sp * g.M * g.N + i];
+    store_elem(g.epi.out, g.epi.out_dt, epi_out_row(g.epi, m) * g.epi.ldy + n, epi_apply<true>(g.epi, m, n, v));
 }
 
 }  // namespace
@@ -95,6 +121,27 @@ int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K
     a.tiles_n = N / FN;
     const int64_t tiles = ((M + FM - 1) / FM) * a.tiles_n;
     if (tiles > 0x7fffffff) { leclip_set_error("gemm(f32): too many tiles"); return LECLIP_E_UNSUPPORTED; }
+    a.tiles = (int)tiles; a.splits = 1; a.kchunk = K; a.partial = nullptr;
+    // few tiles and a long contraction: spread K over ~4 workgroups per CU (each split at least 8 K-steps), partial tiles through a
+    // stream-ordered scratch buffer
+    if (tiles < 128 && K >= 8192) {   // (never a forward shape: those keep the single k-ordered chain, bit-identical across batch sizes)
+        int want = (int)((4 * 256 + tiles - 1) / tiles);
+        const int max_splits = K / (8 * FK);
+        if (want > max_splits) want = max_splits;
+        if (want > 1) {
+            const int kchunk = ((K + want - 1) / want + FK - 1) / FK * FK;
+            const int splits = (K + kchunk - 1) / kchunk;
+            float* ws = nullptr;
+            if (splits > 1 && hipMallocAsync((void**)&ws, (size_t)splits * M * N * sizeof(float), s) == hipSuccess) {
+                a.splits = splits; a.kchunk = kchunk; a.partial = ws;
+                hipLaunchKernelGGL(gemm_f32_64x64x32, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, a);
+                hipLaunchKernelGGL(gemm_f32_reduce, dim3((unsigned)((M * N + 255) / 256)), dim3(256), 0, s, a);
+                (void)hipFreeAsync(ws, s);
+                return leclip_check_launch("gemm_f32_64x64x32 (split-K)");
+            }
+            (void)hipGetLastError();   // no scratch: the unsplit kernel below
+        }
+    }
     hipLaunchKernelGGL(gemm_f32_64x64x32, dim3((unsigned)tiles), dim3(256), 0, s, a);
     return leclip_check_launch("gemm_f32_64x64x32");
 }

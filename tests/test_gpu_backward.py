@@ -78,6 +78,24 @@ def test_attention_bwd(ops, dt, cfg):
     np.testing.assert_allclose(got.double().cpu().numpy(), qr.grad.numpy(), atol=_tol(dt, 3e-5, 8e-3, 6e-2), rtol=0)
 
 
+@pytest.mark.parametrize("shape", [(80, 512, 39424), (128, 64, 8192), (3, 192, 12288)])
+def test_gemm_f32_long_contraction(ops, shape):
+    """The prompt-feature gradients of the local head contract over every caption token (K = 512 x 77) into a handful of output tiles: the
+    exact-fp32 GEMM then splits K over workgroups and adds the partial tiles in index order (csrc/gemm_f32.hip).  Against float64, with a bias
+    and a residual through the reducing kernel's epilogue, and twice for run-to-run identity (no atomics in the reduction)."""
+    m, n, k = shape
+    a = _rand((m, k), 31)
+    w = _rand((n, k), 32)
+    bias = _rand((n,), 33)
+    res = _rand((m, n), 34)
+    ref = a.double() @ w.double().T + bias.double() + res.double()
+    got = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    again = ops.gemm(a.to(DEV), w.to(DEV), bias=bias.to(DEV), residual=res.to(DEV))
+    assert torch.equal(got, again)
+    err = float((got.double().cpu() - ref).abs().max()) / float(ref.abs().max())
+    assert err <= 2e-6, err
+
+
 def _oracle_ctx_grad(arch, sd, ctx0, toks_ctx, feed, labels, loss_name):
     from oracle import clip_oracle as co
     ctx = ctx0.clone().requires_grad_(True)
