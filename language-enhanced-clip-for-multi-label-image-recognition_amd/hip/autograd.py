@@ -95,7 +95,10 @@ class PromptAssembleFunction(torch.autograd.Function):
 
 class CosineLogitsFunction(torch.autograd.Function):
     """logits = scale * normalize(img) @ normalize(txt).T (CDD.py:330-335) with the gradient w.r.t. the text features
-    (image features come from frozen encoders: no gradient): one kernel, leclip_l2norm_logits_bwd."""
+    (image features come from frozen encoders: no gradient).  Backward: g = scale * dlogits^T . normalize(img) is a [C, B] x [B, D]
+    contraction - the exact-fp32 MFMA GEMM on the two transposed operands (it splits a long B over workgroups by itself) - followed by the
+    row-normalisation backward, the same three kernels the local head's backward uses; the one-kernel form (leclip_l2norm_logits_bwd:
+    one workgroup per class walking every image row) remains for feature widths the GEMM does not take."""
 
     @staticmethod
     def forward(ctx, img: torch.Tensor, txt: torch.Tensor, scale: float):
@@ -108,7 +111,11 @@ class CosineLogitsFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dlogits: torch.Tensor):
         img, txt = ctx.saved_tensors
-        return None, ops.l2norm_logits_bwd(img, txt, dlogits.float().contiguous(), ctx.scale), None
+        if img.shape[1] % 64 != 0:
+            return None, ops.l2norm_logits_bwd(img, txt, dlogits.float().contiguous(), ctx.scale), None
+        fhat_t = ops.transpose_f32(ops.l2norm_rows_(img.clone()))                          # [D, B padded to 32]
+        dl_t = ops.transpose_f32(dlogits.float().mul(ctx.scale).contiguous())               # [C, B padded to 32]
+        return None, ops.l2norm_rows_bwd(txt, ops.gemm(dl_t, fhat_t, out_dtype=torch.float32)), None
 
 
 class LocalPoolFunction(torch.autograd.Function):

@@ -96,6 +96,26 @@ def test_gemm_f32_long_contraction(ops, shape):
     assert err <= 2e-6, err
 
 
+@pytest.mark.parametrize("cfg", [(512, 80, 512), (37, 5, 128), (4096, 80, 768), (9, 3, 96)])
+def test_cosine_logits_function_backward(ops, cfg):
+    """d(text features) of scale * normalize(img) @ normalize(txt).T through the autograd function the trainer uses: transposes + exact-fp32
+    GEMM + row-normalisation backward (the last shape, width 96, takes the one-kernel form) against float64 autograd."""
+    from leclip_amd.hip.autograd import CosineLogitsFunction
+    b, c, d = cfg
+    img = _rand((b, d), 41)
+    txt = _rand((c, d), 42)
+    dl = _rand((b, c), 43)
+    tr = txt.double().requires_grad_(True)
+    ref = 4.0 * torch.nn.functional.normalize(img.double(), dim=-1) @ torch.nn.functional.normalize(tr, dim=-1).T
+    ref.backward(dl.double())
+    tg = txt.to(DEV).requires_grad_(True)
+    out = CosineLogitsFunction.apply(img.to(DEV), tg, 4.0)
+    np.testing.assert_allclose(out.double().cpu().detach().numpy(), ref.detach().numpy(), atol=2e-5, rtol=0)
+    out.backward(dl.to(DEV))
+    err = float((tg.grad.double().cpu() - tr.grad).abs().max()) / float(tr.grad.abs().max())
+    assert err <= 5e-6, err
+
+
 def _oracle_ctx_grad(arch, sd, ctx0, toks_ctx, feed, labels, loss_name):
     from oracle import clip_oracle as co
     ctx = ctx0.clone().requires_grad_(True)
