@@ -830,7 +830,7 @@ int leclip_cu_count() {
 }
 int leclip_gemm256_cus() { return leclip_cu_count(); }
 
-// Shapes this kernel takes: N % 256 == 0, K % 64 == 0, K >= 128; worth it only when the grid fills the chip.
+// Shapes this kernel takes: N % 256 == 0, K % 64 == 0, K >= 128; worth it from about a third of the chip's CUs upwards.
 bool leclip_gemm256_eligible(int64_t M, int N, int K) {
     if (N % TN != 0 || K % TK != 0 || K < 2 * TK) return false;
 #ifdef LECLIP_DIAG
@@ -840,7 +840,10 @@ bool leclip_gemm256_eligible(int64_t M, int N, int K) {
     if (forced == 128) return false;
 #endif
     const int64_t tiles = ((M + TM - 1) / TM) * (N / TN);
-    return tiles >= 192;
+    // 96 since round 4 (was 192): on the tuning steps' text-tower shapes (M = 18 480 / 6 160, N = 512 .. 2 048) a 146- or 150-tile problem runs
+    // faster on 146 CUs with this kernel than as 580 tiles of the 128 x 128 family - DenseCLIP caption step +8 %, profiles/ab_tune.sh; 64 and 40
+    // lose on the M = 6 160 shapes.  Both families produce the same bits, so the threshold is a rate decision only.
+    return tiles >= 96;
 }
 
 int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
