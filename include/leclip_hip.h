@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define LECLIP_ABI_VERSION 8
+#define LECLIP_ABI_VERSION 9
 
 typedef enum { LECLIP_F32 = 0, LECLIP_F16 = 1, LECLIP_BF16 = 2 } leclip_dtype;
 typedef enum { LECLIP_ACT_NONE = 0, LECLIP_ACT_QUICKGELU = 1 } leclip_act;
@@ -46,6 +46,12 @@ const char* leclip_last_error(void);
  * residual block; profiles/r04_walk_order.txt).  The reference has no counterpart (its kernels are the vendor's, clip/model.py:213-228).
  * Returns the previous hint. */
 int leclip_set_walk_order(int order);
+/* GEMM kernel-family override for the NEXT launches issued by the calling thread (thread-local; results never depend on it - the three 16-bit
+ * families feed v_mfma_f32_16x16x32 the same ascending K sequence and share one epilogue arithmetic, tests/test_gpu_parity.py holds them to bit
+ * identity with this switch): 128 = gemm_tn_128x128x64, 256 = gemm_tn_256x256x64_pp, 384 = gemm_tn_384x256x32_pp (ABI 9, round 5), anything else =
+ * the library's rate heuristic (tile count).  A family that cannot run a call (shape, epilogue) falls through to the next smaller one.  The
+ * reference has no counterpart (its GEMMs are the vendor's, clip/model.py:213-228).  Returns the previous override (-1 = none). */
+int leclip_set_gemm_family(int family);
 /* Name of the device kernel family a GEMM call with these arguments dispatches to (for profiles/tests). */
 const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_dtype ab_dtype);
 

@@ -34,6 +34,14 @@ extern "C" int leclip_set_walk_order(int order) {
     return prev;
 }
 
+thread_local int g_leclip_gemm_family = -1;
+int leclip_gemm_family() { return g_leclip_gemm_family; }
+extern "C" int leclip_set_gemm_family(int family) {
+    const int prev = g_leclip_gemm_family;
+    g_leclip_gemm_family = (family == 128 || family == 256 || family == 384) ? family : -1;
+    return prev;
+}
+
 extern "C" const char* leclip_strerror(int code) {
     switch (code) {
         case LECLIP_OK: return "ok";

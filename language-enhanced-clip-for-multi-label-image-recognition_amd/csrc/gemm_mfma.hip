@@ -236,6 +236,10 @@ int launch_128(const void* A, const void* W, int64_t M, int N, int K, int64_t ld
                int ab_dtype, hipStream_t s);
 int leclip_gemm256_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                           const EpiParams& epi, int ab_dtype, hipStream_t s);
+bool leclip_gemm384_eligible(int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& e, int ab_dtype);
+bool leclip_gemm384_shape(int64_t M, int N, int K);
+int leclip_gemm384_launch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& epi, int ab_dtype,
+                          hipStream_t s);
 
 int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, int64_t lda, int64_t ldw,
                          const EpiParams& epi, int ab_dtype, hipStream_t s) {
@@ -259,6 +263,8 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
     // One kernel family per call, chosen from (M, N, K) alone and covering every row: an image's result must not depend on
     // where its rows sit in the batch (round 1 sent the trailing tile rows of a large batch to the 128x128 kernel, whose
     // MFMA shape sums K in a different order - sharded logits then differed from unsharded ones in the last bits).
+    // (three families since round 5, all on v_mfma_f32_16x16x32 with ascending K and one epilogue arithmetic: the same bits from each)
+    if (leclip_gemm384_eligible(M, N, K, lda, ldw, epi, ab_dtype)) return leclip_gemm384_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     return launch_128(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
 }
@@ -278,6 +284,9 @@ extern "C" const char* leclip_gemm_kernel_name(int64_t M, int N, int K, leclip_d
     (void)M;
     if (ab_dtype == LECLIP_F32) return (N % 64 == 0 && K % 32 == 0) ? "gemm_f32_64x64x32" : "unsupported";
     if (N % BN != 0 || K % BK != 0) return "unsupported";
+    // (the 384 x 256 kernel takes the residual / fused-LayerNorm / plain 16-bit epilogues of a shape it is eligible for; fp32 output, row remap and
+    // the im2col gather stay with the 256 x 256 kernel)
+    if (leclip_gemm384_shape(M, N, K)) return "gemm_tn_384x256x32_pp";
     return leclip_gemm256_eligible(M, N, K) ? "gemm_tn_256x256x64_pp" : "gemm_tn_128x128x64";
 }
 

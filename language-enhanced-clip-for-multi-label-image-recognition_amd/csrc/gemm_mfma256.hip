@@ -839,6 +839,9 @@ bool leclip_gemm256_eligible(int64_t M, int N, int K) {
     if (forced == 256) return true;
     if (forced == 128) return false;
 #endif
+    const int fam = leclip_gemm_family();   // leclip_set_gemm_family: tests compare the families on one call
+    if (fam == 256) return true;
+    if (fam == 128) return false;
     const int64_t tiles = ((M + TM - 1) / TM) * (N / TN);
     // 96 since round 4 (was 192): on the tuning steps' text-tower shapes (M = 18 480 / 6 160, N = 512 .. 2 048) a 146- or 150-tile problem runs
     // faster on 146 CUs with this kernel than as 580 tiles of the 128 x 128 family - DenseCLIP caption step +8 %, profiles/ab_tune.sh; 64 and 40

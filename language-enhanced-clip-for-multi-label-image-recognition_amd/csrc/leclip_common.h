@@ -39,6 +39,7 @@ __device__ __forceinline__ void wglog_end(const WgLog& w, unsigned tag, unsigned
 }
 #endif
 int leclip_walk_order();   // capi.hip: the calling thread's walk-order hint (-1 default, 0 ascending, 1 descending)
+int leclip_gemm_family();  // capi.hip: the calling thread's GEMM kernel-family override (-1 = the library's rate heuristic; 128 / 256 / 384)
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 template <typename T> struct VecOf;

@@ -353,11 +353,83 @@ static void stamps() {
     }
 }
 
+// Round 5: the 384 x 256 GEMM family against the 256 x 256 one on the same call (leclip_set_gemm_family), bit for bit, every flavour the new
+// kernel has - residual (+ LayerNorm partials), fused LayerNorm (+ QuickGELU), plain bias (+ QuickGELU) - ragged M, K-step counts 3 .. 96 with
+// every remainder mod 3 (the ring rotates), then timings of both families on the ViT-B/16 shapes.
+static int g384() {
+    struct C { int64_t M; int N, K; } cases[] = {{50432, 768, 768}, {50432 - 100, 768, 3072}, {30000, 2304, 768}, {20001, 3072, 768}, {1000, 256, 192},
+                                                {777, 512, 128}, {2500, 256, 320}, {4000, 1024, 1024}, {385, 256, 4096}, {383, 256, 128}};
+    const bool timing_only = getenv("LECLIP_G384_BENCH_ONLY") != nullptr;
+    if (!timing_only) for (int dt : {LECLIP_F16, LECLIP_BF16}) for (auto& c : cases) {
+        const int64_t M = c.M; const int N = c.N, K = c.K;
+        auto A = randn(M * K), W = randn((size_t)N * K, 1.f / std::sqrt((float)K)), Bv = randn(N), R = randn(M * N), CS = randn(N);
+        std::vector<float> ST(2 * M);
+        { std::uniform_real_distribution<float> u(0.5f, 1.5f); std::normal_distribution<float> n(0.f, 0.1f); for (int64_t m = 0; m < M; ++m) { ST[2 * m] = n(rng); ST[2 * m + 1] = u(rng); } }
+        auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
+        const size_t ybytes = (size_t)(M + 8) * N * 2, pbytes = (size_t)(N / 64) * M * 8 + 64;
+        Buf dA(Ap.size()), dW(Wp.size()), dB(N * 4), dR(Rp.size()), dCS(N * 4), dST(ST.size() * 4), dY(ybytes), dP(pbytes);
+        dA.up(Ap.data()); dW.up(Wp.data()); dB.up(Bv.data()); dR.up(Rp.data()); dCS.up(CS.data()); dST.up(ST.data());
+        struct F { const char* name; bool res, stats, ln; int act; } flav[] = {{"res+stats", true, true, false, 0}, {"res", true, false, false, 0}, {"ln", false, false, true, 0},
+                                                                              {"ln+gelu", false, false, true, 1}, {"bias", false, false, false, 0}, {"bias+gelu", false, false, false, 1}};
+        for (auto& f : flav) {
+            std::vector<uint8_t> y[2], pp[2];
+            int rc = 0;
+            for (int fam = 0; fam < 2; ++fam) {
+                HIPCHK(hipMemset(dY.d, 0xEE, ybytes)); HIPCHK(hipMemset(dP.d, 0xEE, pbytes));
+                leclip_set_gemm_family(fam ? 384 : 256);
+                rc |= leclip_gemm_ln_fused_fwd(dA.d, dW.d, (float*)dB.d, f.ln ? (float*)dST.d : nullptr, f.ln ? (float*)dCS.d : nullptr, f.res ? dR.d : nullptr, dY.d,
+                                               f.stats ? (float*)dP.d : nullptr, M, N, K, K, K, N, N, (leclip_act)f.act, (leclip_dtype)dt, (leclip_dtype)dt, (leclip_dtype)dt, nullptr);
+                HIPCHK(hipDeviceSynchronize());
+                leclip_set_gemm_family(-1);
+                y[fam].resize(ybytes); pp[fam].resize(pbytes);
+                dY.down(y[fam].data()); dP.down(pp[fam].data());
+            }
+            size_t bad = 0, first = 0;
+            for (size_t i = 0; i < ybytes; ++i) if (y[0][i] != y[1][i]) { if (!bad) first = i; ++bad; }
+            size_t badp = 0;
+            for (size_t i = 0; i < pbytes; ++i) if (pp[0][i] != pp[1][i]) ++badp;
+            // guard rows (past M) and the partials' tail must still hold the fill pattern
+            size_t guard = 0;
+            for (size_t i = (size_t)M * N * 2; i < ybytes; ++i) if (y[1][i] != 0xEE) ++guard;
+            for (size_t i = (size_t)(N / 64) * M * 8; i < pbytes; ++i) if (pp[1][i] != 0xEE) ++guard;
+            const bool ok = !rc && !bad && !badp && !guard;
+            printf("%s g384 %-9s %s M=%lld N=%d K=%d: rc %d, %zu output bytes differ (first at element %zu = row %zu col %zu), %zu partial bytes differ, %zu guard bytes touched\n",
+                   ok ? "ok  " : "FAIL", f.name, dtn(dt), (long long)M, N, K, rc, bad, first / 2, first / 2 / N, first / 2 % N, badp, guard);
+            if (!ok) g_fail++;
+        }
+    }
+    printf(g_fail ? "FAILED %d checks\n" : "ALL OK\n", g_fail);
+    if (g_fail) return 1;
+    const int64_t Ms[2] = {256 * 197, 128 * 197};
+    struct S { int N, K, act; bool res, ln; const char* name; } shapes[] = {
+        {2304, 768, 0, false, true, "qkv(ln)"}, {768, 768, 0, true, false, "out_proj(res+stats)"}, {3072, 768, 1, false, true, "c_fc(ln+gelu)"}, {768, 3072, 0, true, false, "c_proj(res+stats)"}};
+    for (int64_t M : Ms) for (int dt : {LECLIP_F16}) for (auto& s : shapes) {
+        auto A = randn(M * s.K), W = randn((size_t)s.N * s.K, 0.03f), Bv = randn(s.N), R = randn(M * s.N), CS = randn(s.N);
+        std::vector<float> ST(2 * M, 1.f);
+        auto Ap = pack(A, dt), Wp = pack(W, dt), Rp = pack(R, dt);
+        Buf dA(Ap.size()), dW(Wp.size()), dB(s.N * 4), dR(Rp.size()), dCS(s.N * 4), dST(ST.size() * 4), dY((size_t)M * s.N * 2), dP((size_t)(s.N / 64) * M * 8);
+        dA.up(Ap.data()); dW.up(Wp.data()); dB.up(Bv.data()); dR.up(Rp.data()); dCS.up(CS.data()); dST.up(ST.data());
+        double t[2][3];
+        for (int round = 0; round < 3; ++round) for (int fam = 0; fam < 2; ++fam) {
+            leclip_set_gemm_family(fam ? 384 : 256);
+            t[fam][round] = time_ms(20, [&] {
+                leclip_gemm_ln_fused_fwd(dA.d, dW.d, (float*)dB.d, s.ln ? (float*)dST.d : nullptr, s.ln ? (float*)dCS.d : nullptr, s.res ? dR.d : nullptr, dY.d,
+                                         s.res ? (float*)dP.d : nullptr, M, s.N, s.K, s.K, s.K, s.N, s.N, (leclip_act)s.act, (leclip_dtype)dt, (leclip_dtype)dt, (leclip_dtype)dt, nullptr);
+            });
+            leclip_set_gemm_family(-1);
+        }
+        printf("bench %-20s %s M=%lld: 256x256 %.1f / %.1f / %.1f us   384x256 %.1f / %.1f / %.1f us   (%.0f -> %.0f TFLOP/s)\n", s.name, dtn(dt), (long long)M, t[0][0] * 1e3,
+               t[0][1] * 1e3, t[0][2] * 1e3, t[1][0] * 1e3, t[1][1] * 1e3, t[1][2] * 1e3, 2.0 * M * s.N * s.K / t[0][2] * 1e-9, 2.0 * M * s.N * s.K / t[1][2] * 1e-9);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     printf("leclip ABI %d\n", leclip_abi_version());
     if (argc > 1 && !strcmp(argv[1], "bench")) { bench(); return 0; }
     if (argc > 1 && !strcmp(argv[1], "stamps")) { stamps(); return 0; }
     if (argc > 1 && !strcmp(argv[1], "attn")) { return attn(); }
+    if (argc > 1 && !strcmp(argv[1], "g384")) { return g384(); }
     if (argc > 1 && !strcmp(argv[1], "attnstamps")) { return attnstamps(); }
     check_gemm_identity();
     for (int dt : {LECLIP_BF16, LECLIP_F16}) {

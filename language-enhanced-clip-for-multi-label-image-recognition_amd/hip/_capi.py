@@ -11,7 +11,7 @@ from ctypes import c_char_p, c_float, c_int, c_int64, c_void_p
 
 PACKAGE_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB_PATH = os.path.join(PACKAGE_DIR, "lib", "libleclip_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 F32, F16, BF16 = 0, 1, 2
 ACT_NONE, ACT_QUICKGELU = 0, 1
@@ -32,6 +32,7 @@ SIGNATURES = {
     "leclip_strerror": (c_char_p, [c_int]),
     "leclip_last_error": (c_char_p, []),
     "leclip_set_walk_order": (c_int, [c_int]),
+    "leclip_set_gemm_family": (c_int, [c_int]),
     "leclip_gemm_kernel_name": (c_char_p, [c_int64, c_int, c_int, c_int]),
     "leclip_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64,
                                      c_float, c_int, c_int, c_void_p]),

@@ -45,6 +45,12 @@ class _Timed:
         return False
 
 
+def set_gemm_family(family: int) -> int:
+    """GEMM kernel-family override for the calling thread's next launches (leclip_set_gemm_family): 128 / 256 / 384, anything else = the
+    library's rate heuristic.  Results never depend on it (the families are bit-identical); tests and A/B timings use it.  Returns the previous override."""
+    return _capi.load().leclip_set_gemm_family(int(family))
+
+
 def set_walk_order(order: int) -> int:
     """Walk-order hint for the calling thread's next launches (leclip_set_walk_order): 0 ascending rows, 1 descending, -1 library default.
     Which rows a workgroup takes first, never what it computes.  Returns the previous hint."""

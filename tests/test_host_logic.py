@@ -29,7 +29,11 @@ def test_library_exports_every_declared_symbol():
     assert declared == set(_capi.SIGNATURES), "ctypes binding and header disagree"
     assert _capi.load().leclip_abi_version() == _capi.ABI_VERSION
     assert _capi.load().leclip_strerror(-2) == b"unsupported shape or dtype"
-    assert _capi.load().leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) in (b"gemm_tn_128x128x64", b"gemm_tn_256x256x64_pp")
+    assert _capi.load().leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) in (b"gemm_tn_128x128x64", b"gemm_tn_256x256x64_pp", b"gemm_tn_384x256x32_pp")
+    prev = _capi.load().leclip_set_gemm_family(256)   # thread-local override (ABI 9): host-side bookkeeping, no device needed
+    assert prev == -1 and _capi.load().leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) == b"gemm_tn_256x256x64_pp"
+    assert _capi.load().leclip_set_gemm_family(384) == 256 and _capi.load().leclip_gemm_kernel_name(1000, 768, 768, _capi.BF16) == b"gemm_tn_384x256x32_pp"
+    assert _capi.load().leclip_set_gemm_family(-1) == 384
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
