@@ -265,7 +265,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
             p.template step<EPI_OPS>(kbyte, st, wsel);
         }
 
-        // ---- epilogue
+        // ---- epilogue, two passes.
+        // Pass 1, column block by column block (j outer, the six strips inner): the block's constants are read from LDS ONCE per tile, the branch
+        // value (bias / fused LayerNorm / QuickGELU) is computed in the accumulator layout and rounded to T in place - 4 fp32 registers become 2 -
+        // and the registers that frees take the residual chunks of strips 0..3, two loads per block: 16 are in flight when pass 1 ends, their
+        // latency under its arithmetic (the strip-major first version read the constants 6 times and waited for the first chunks on the spot);
+        // strips 4 and 5 follow from pass 2 as it frees registers.
+        // Pass 2, strip by strip: park the 16 x 128 strip (8 ds_write_b64), read it back 16 lanes per row, add the residual, store, partials.
         const int64_t em0 = m0;
         const int en0 = n0;
         int lane_e = lane;   // laundered: what derives from it is recomputed per tile instead of living across the K loop
@@ -274,7 +280,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
         const int64_t left = g.M - row0;
         const int rows_ok = left >= 96 ? 96 : (left > 0 ? (int)left : 0);
         // residual chunks: inline-asm buffer loads with counted waits (tests/isa_audit.py checks that nothing touches a destination between a
-        // load and the wait that names it); chunk (strip q, pass pp) of this lane = row 16 q + 4 pp + (lane >> 4), columns 8 (lane & 15) ..
+        // load and the wait that names it); chunk 4 q + pp of this lane = row 16 q + 4 pp + (lane >> 4), columns 8 (lane & 15) ..
         i32x4 rpre[PF == 1 ? 24 : 1];
         const int ldrb = PF == 1 ? __builtin_amdgcn_readfirstlane((int)e.ldr * 2) : 0;
         i32x4 rdesc = {0, 0, 0, 0};
@@ -286,54 +292,39 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
             rdesc[3] = 0x00020000;
         }
         const int rvoff = PF == 1 ? (lane_e >> 4) * ldrb + (lane_e & 15) * 16 : 0;
-        auto load_res4 = [&](int q) {
+        auto load_res = [&](int first, int n) {   // chunks first .. first + n - 1
 #pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int off = rvoff + (q * 16 + pp * 4) * ldrb;
-                if (pp == 0) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? 4 * q + pp : 0]) : "v"(off), "s"(rdesc) : "memory");
-                else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? 4 * q + pp : 0]) : "v"(off), "s"(rdesc) : "memory");
+            for (int c = first; c < first + n; ++c) {
+                const int off = rvoff + ((c >> 2) * 16 + (c & 3) * 4) * ldrb;
+                if (c == first) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? c : 0]) : "v"(off), "s"(rdesc) : "memory");
+                else asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(rpre[PF == 1 ? c : 0]) : "v"(off), "s"(rdesc) : "memory");
             }
         };
-        if constexpr (PF == 1) load_res4(0);
         PIN();
         if (grp == 0) __builtin_amdgcn_s_barrier();   // re-align the two groups (equal barrier counts)
         PIN();
 
+        v4t wq[6][8];   // the tile's branch values, rounded to T: lane (m = l & 15, g = l >> 4) holds row 16 q + m, columns 16 j + 4 g .. + 3
         {
-            char* st = smem + STRIPS_OFF + wave * STRIP;
             const float* cst = (const float*)(smem + CST_OFF);
-            const int ldb = __builtin_amdgcn_readfirstlane((int)e.ldy * 2);
-            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-                uniform_ptr384((const char*)e.out + (row0 * e.ldy + en0 + wn * 128) * 2), 0,
-                __builtin_amdgcn_readfirstlane(rows_ok ? (rows_ok - 1) * ldb + 256 : 0), 0x00020000);
-            __amdgpu_buffer_rsrc_t srsrc;
-            if constexpr (STATS == 1)   // partials, slot-major [slot][row][2]: the wave's two slots, rows from row0; lanes address (slot, row) themselves
-                srsrc = __builtin_amdgcn_make_buffer_rsrc(
-                    uniform_ptr384((const char*)e.stats_out + ((int64_t)((en0 + wn * 128) >> 6) * e.stats_rows + row0) * 8), 0,
-                    __builtin_amdgcn_readfirstlane((int)((e.stats_rows + rows_ok) * 8)), 0x00020000);
-            auto park16 = [&](int q) {
-                int ln_ = lane_e;
-                asm volatile("" : "+v"(ln_));
-                const int m = ln_ & 15, gq = ln_ >> 4;
-                char* sq = st + m * PITCH + gq * 8;
-                const float* cb = cst + wn * 128 + 4 * gq;
-                float mean = 0.f, rstd = 1.f;
-                if constexpr (PF == 2) {
-                    const f32x2 mr = *(const f32x2*)(cst + 512 + 2 * (wm * 96 + q * 16 + m));
-                    mean = mr[0];
-                    rstd = mr[1];
-                }
-                // column constants one block ahead: a strip's worth (32 + 32 registers) does not fit beside the accumulators, and a read that is
-                // waited for on the spot costs an LDS round trip per block
-                f32x4 bn = *(const f32x4*)cb, sn = {0.f, 0.f, 0.f, 0.f};
-                if constexpr (PF == 2) sn = *(const f32x4*)(cb + 256);
+            const int m = lane_e & 15, gq = lane_e >> 4;
+            const float* cb = cst + wn * 128 + 4 * gq;
+            f32x2 mr[PF == 2 ? 6 : 1];
+            if constexpr (PF == 2) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const f32x4 b4 = bn, s4 = sn;
-                    if (j + 1 < 8) {
-                        bn = *(const f32x4*)(cb + 16 * (j + 1));
-                        if constexpr (PF == 2) sn = *(const f32x4*)(cb + 256 + 16 * (j + 1));
-                    }
+                for (int q = 0; q < 6; ++q) mr[q] = *(const f32x2*)(cst + 512 + 2 * (wm * 96 + q * 16 + m));
+            }
+            f32x4 bn = *(const f32x4*)cb, sn = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (PF == 2) sn = *(const f32x4*)(cb + 256);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f32x4 b4 = bn, s4 = sn;
+                if (j + 1 < 8) {
+                    bn = *(const f32x4*)(cb + 16 * (j + 1));
+                    if constexpr (PF == 2) sn = *(const f32x4*)(cb + 256 + 16 * (j + 1));
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) {
                     v4t w;
 #pragma unroll
                     for (int r = 0; r < 4; r += 2) {
@@ -343,7 +334,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                         const f2 bb = {b4[r], b4[r + 1]};
                         if constexpr (PF == 2) {
                             const f2 ss = {s4[r], s4[r + 1]};
-                            v = __builtin_elementwise_fma((f2)(rstd), __builtin_elementwise_fma((f2)(-mean), ss, v), bb);
+                            v = __builtin_elementwise_fma((f2)(mr[q][1]), __builtin_elementwise_fma((f2)(-mr[q][0]), ss, v), bb);
                         } else v += bb;
                         if constexpr (ACT == 1) {
                             const f2 t = v * (f2)(-2.4554669595930157f);
@@ -355,15 +346,33 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                         w[r] = (T)v.x;
                         w[r + 1] = (T)v.y;
                     }
-                    *(v4t*)(sq + j * 32) = w;
-                    PIN();
+                    wq[q][j] = w;
                 }
-            };
-            park16(0);
-            PIN();
-            if constexpr (PF == 1) load_res4(1);   // (strip 0's 32 accumulator registers are free now)
+                PIN();
+                if constexpr (PF == 1) load_res(2 * j, 2);   // (block j's 24 accumulator registers became 12: room for two chunks and pass 2's temporaries)
+                PIN();
+            }
+        }
+
+        {
+            char* st = smem + STRIPS_OFF + wave * STRIP;
+            const int ldb = __builtin_amdgcn_readfirstlane((int)e.ldy * 2);
+            const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+                uniform_ptr384((const char*)e.out + (row0 * e.ldy + en0 + wn * 128) * 2), 0,
+                __builtin_amdgcn_readfirstlane(rows_ok ? (rows_ok - 1) * ldb + 256 : 0), 0x00020000);
+            __amdgpu_buffer_rsrc_t srsrc;
+            if constexpr (STATS == 1)   // partials, slot-major [slot][row][2]: the wave's two slots, rows from row0; lanes address (slot, row) themselves
+                srsrc = __builtin_amdgcn_make_buffer_rsrc(
+                    uniform_ptr384((const char*)e.stats_out + ((int64_t)((en0 + wn * 128) >> 6) * e.stats_rows + row0) * 8), 0,
+                    __builtin_amdgcn_readfirstlane((int)((e.stats_rows + rows_ok) * 8)), 0x00020000);
             int lane_q = lane_e;
             asm volatile("" : "+v"(lane_q));
+            char* sq = st + (lane_q & 15) * PITCH + (lane_q >> 4) * 8;
+            auto park = [&](int q) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) *(v4t*)(sq + j * 32) = wq[q][j];
+            };
+            park(0);
             const int crow = lane_q >> 4, c16 = (lane_q & 15) * 16;
             const int voff = crow * ldb + c16;
             const int cc = lane_q & 7;
@@ -378,22 +387,22 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                     for (int c = 0; c < 4; ++c) { o[pp][c] = r0[c]; o[pp][4 + c] = r1[c]; }
                 }
                 PIN();
-                if (q + 1 < 6) park16(q + 1);
+                if (q + 1 < 6) park(q + 1);   // (a wave's LDS operations execute in order: behind the read-back, no wait needed)
                 PIN();
                 if constexpr (PF == 1) {
-                    if (q + 2 < 6) load_res4(q + 2);
-                    // strip q's chunks: everything but the operations issued behind them
-                    //   q = 0: L1 L2 | 1: L2 S0 L3 | 2: S0 L3 S1 L4 | 3: S1 L4 S2 L5 | 4: S2 L5 S3 | 5: S3 S4      (L = 4 loads, S = 4 + STATS stores)
+                    // queue: L0-15 (pass 1) | S0 | L16-19 . S1 | L20-23 . S2 | S3 | S4 | S5     (L = residual chunks, S = a strip's 4 + STATS stores)
+                    if (q == 1 || q == 2) load_res(12 + 4 * q, 4);
                     constexpr int SS = 4 + STATS;
 #define RES_WAIT(N)                                                                                                                                   \
     asm volatile("s_waitcnt vmcnt(%4)"                                                                                                                \
                  : "+v"(rpre[PF == 1 ? 4 * q : 0]), "+v"(rpre[PF == 1 ? 4 * q + 1 : 0]), "+v"(rpre[PF == 1 ? 4 * q + 2 : 0]), "+v"(rpre[PF == 1 ? 4 * q + 3 : 0]) \
                  : "n"(N) : "memory")
-                    if (q == 0) RES_WAIT(8);
-                    else if (q == 1) RES_WAIT(8 + SS);
-                    else if (q == 2 || q == 3) RES_WAIT(8 + 2 * SS);
-                    else if (q == 4) RES_WAIT(4 + 2 * SS);
-                    else RES_WAIT(2 * SS);
+                    if (q == 0) RES_WAIT(12);
+                    else if (q == 1) RES_WAIT(12 + SS);
+                    else if (q == 2) RES_WAIT(12 + 2 * SS);
+                    else if (q == 3) RES_WAIT(8 + 3 * SS);
+                    else if (q == 4) RES_WAIT(4 + 3 * SS);
+                    else RES_WAIT(3 * SS);
 #undef RES_WAIT
 #pragma unroll
                     for (int pp = 0; pp < 4; ++pp) {
@@ -408,8 +417,13 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                 if constexpr (STATS == 1) {
                     // LayerNorm partials of the stored values: the 8 lanes of a (row, 64-column slot) hold its pair; lane cc < 4 of each group stores
                     // the pair of pass cc's row - one store per strip: two 128-byte runs (16 rows x 8 bytes) in the wave's two slots
-                    const f32x2 s0 = row_block_stats(o[0]), s1 = row_block_stats(o[1]), s2 = row_block_stats(o[2]), s3 = row_block_stats(o[3]);
-                    const f32x2 sel = cc == 0 ? s0 : cc == 1 ? s1 : cc == 2 ? s2 : s3;
+                    f32x2 sel = row_block_stats(o[0]);
+#pragma unroll
+                    for (int pp = 1; pp < 4; ++pp) {   // (one pass at a time: four interleaved cost 32 temporaries the residual flavours do not have)
+                        PIN();
+                        const f32x2 sp = row_block_stats(o[pp]);
+                        sel = cc == pp ? sp : sel;
+                    }
                     const int r = q * 16 + cc * 4 + crow;
                     const int svoff = (cc < 4 && r < rows_ok) ? (int)((((lane_q >> 3) & 1) * e.stats_rows + r) * 8) : 0x7ff00000;
                     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, sel), srsrc, svoff, 0, 0);
