@@ -155,39 +155,41 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
         after = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
         last = len(blocks) - 1
         walk = _Walk(walk)
-        for i, p in enumerate(blocks):
-            if cls_last and i == last:
-                walk.done()
-                x_c = x.view(batch, tokens * d)[:, :d]             # class rows in place: [B, d] with row stride T*d
-                cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
-                if "ln_partials" in src:
-                    # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only
-                    ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
-                    ops.gather_rows(ws.partials.view(-1, 2), ws.cls_pair_index, out=ws.cls_partials.view(-1, 2))
-                    ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], **cls)
-                else:   # (a one-block tower without fused patch statistics: the whole qkv GEMM)
-                    ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
-                ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx, q_rows=1)
-                ctx_c = ws.ctx.view(batch, tokens * d)[:, :d]
-                ops.gemm_ln(ctx_c, p.w_o, p.b_o, residual=x_c, stats_out=ws.cls_partials, out=ws.cls_x)
-                ops.gemm_ln(ws.cls_x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.cls_u, **cls)
-                ops.gemm(ws.cls_u, p.w_pr, p.b_pr, residual=ws.cls_x, out=ws.cls_x)
-                return ws.cls_x
-            walk.set("qkv")
-            ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
-            walk.set("attention")
-            ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
-            walk.set("out_proj")
-            ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
-            walk.set("c_fc")
-            ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
-            walk.set("c_proj")
-            if i < last:
-                ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
-                src = after
-            else:
-                ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
-        walk.done()
+        try:   # (an exception mid-block must not leave the calling thread's walk-order hint set for later launches)
+            for i, p in enumerate(blocks):
+                if cls_last and i == last:
+                    walk.done()
+                    x_c = x.view(batch, tokens * d)[:, :d]             # class rows in place: [B, d] with row stride T*d
+                    cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
+                    if "ln_partials" in src:
+                        # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only
+                        ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
+                        ops.gather_rows(ws.partials.view(-1, 2), ws.cls_pair_index, out=ws.cls_partials.view(-1, 2))
+                        ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], **cls)
+                    else:   # (a one-block tower without fused patch statistics: the whole qkv GEMM)
+                        ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
+                    ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx, q_rows=1)
+                    ctx_c = ws.ctx.view(batch, tokens * d)[:, :d]
+                    ops.gemm_ln(ctx_c, p.w_o, p.b_o, residual=x_c, stats_out=ws.cls_partials, out=ws.cls_x)
+                    ops.gemm_ln(ws.cls_x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.cls_u, **cls)
+                    ops.gemm(ws.cls_u, p.w_pr, p.b_pr, residual=ws.cls_x, out=ws.cls_x)
+                    return ws.cls_x
+                walk.set("qkv")
+                ops.gemm_ln(x, p.wf_qkv, p.cb_qkv, ln_colsum=p.cs_qkv, out=ws.qkv, **src)
+                walk.set("attention")
+                ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
+                walk.set("out_proj")
+                ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
+                walk.set("c_fc")
+                ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
+                walk.set("c_proj")
+                if i < last:
+                    ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
+                    src = after
+                else:
+                    ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
+        finally:
+            walk.done()
         return x
     for i, p in enumerate(blocks):
         ops.layernorm(x, p.ln1_w, p.ln1_b, out=ws.h)

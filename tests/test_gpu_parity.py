@@ -78,10 +78,12 @@ def test_gemm(ops, dt, shape, epi):
 
 
 def test_gemm_kernel_families(ops):
-    """The dispatcher: 256x256 ping-pong kernel when the grid fills the chip, 128x128 otherwise; both against fp64."""
+    """The dispatcher: the 384x256 ping-pong kernel (round 5) from 160 of its tiles up, the 256x256 one from 96 of its tiles, 128x128 otherwise;
+    against fp64."""
     from leclip_amd.hip import _capi
     lib = _capi.load()
-    assert lib.leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) == b"gemm_tn_256x256x64_pp"
+    assert lib.leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) == b"gemm_tn_384x256x32_pp"
+    assert lib.leclip_gemm_kernel_name(12608, 768, 768, _capi.BF16) == b"gemm_tn_256x256x64_pp"      # 99 tiles of 384x256, 150 of 256x256
     assert lib.leclip_gemm_kernel_name(1576, 768, 768, _capi.BF16) == b"gemm_tn_128x128x64"
     assert lib.leclip_gemm_kernel_name(50432, 768, 768, _capi.F32) == b"gemm_f32_64x64x32"
     assert lib.leclip_gemm_kernel_name(50432, 100, 768, _capi.BF16) == b"unsupported"
@@ -139,10 +141,21 @@ def test_gemm_inplace_residual_and_errors(ops):
         ops.gemm(a.cpu(), w.cpu())
 
 
+@pytest.fixture
+def family(ops, request):
+    """Runs a test under a GEMM kernel-family override (leclip_set_gemm_family; thread-local, restored afterwards)."""
+    prev = ops.set_gemm_family(request.param)
+    yield request.param
+    ops.set_gemm_family(prev)
+
+
+@pytest.mark.parametrize("family", [256, 384], indirect=True)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 @pytest.mark.parametrize("shape", [(6160, 2048, 512), (50332, 768, 768), (50000, 512, 320), (49000, 512, 128)])
-def test_gemm256_specialised_epilogues(ops, dt, shape):
-    """Shapes with >= 192 tiles of 256x256 run the persistent kernel; each of its compile-time epilogues (bias, +QuickGELU,
+def test_gemm256_specialised_epilogues(ops, dt, shape, family):
+    """Both persistent kernel families (256x256x64 and, round 5, 384x256x32: ring of three 32-deep steps - K = 320 / 512 / 768 / 128 are 10 / 16 / 24 /
+    4 steps, every remainder mod 3; fp32-output calls fall through to the 256x256 kernel there).
+    Shapes with >= 192 tiles of 256x256 run the persistent kernel; each of its compile-time epilogues (bias, +QuickGELU,
     +residual, +residual+LayerNorm partial sums, fused LayerNorm, fused LayerNorm+QuickGELU) against fp32 torch on the
     device, with a ragged last tile row (M % 256 != 0) and, for the second shape, a third round that fills a third of the CUs;
     K = 320 has an odd number of K-tiles (no cross-tile pipelining: prologue between tiles), K = 128 the minimum of two."""
@@ -154,7 +167,7 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
     res = torch.randn(M, N, generator=g).to(dt).to(DEV)
     stats = torch.stack([torch.randn(M, generator=g) * 0.1, torch.rand(M, generator=g) + 0.5], dim=1).contiguous().to(DEV)
     colsum = torch.randn(N, generator=g).to(DEV)
-    assert ops._capi.load().leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)).decode().startswith("gemm_tn_256x256x64")
+    assert ops._capi.load().leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)).decode().startswith("gemm_tn_%dx256" % family)
     ref0 = a.float() @ w.float().t()
     gelu = lambda x: x * torch.sigmoid(1.702 * x)
     lnref = stats[:, 1:2] * (ref0 - stats[:, 0:1] * colsum[None, :]) + bias
@@ -178,14 +191,15 @@ def test_gemm256_specialised_epilogues(ops, dt, shape):
     check(ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=ops.ACT_QUICKGELU), gelu(lnref))
 
 
+@pytest.mark.parametrize("family", [256, 384], indirect=True)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-def test_gemm256_edge_tiles_write_nothing_past_m(ops, dt):
+def test_gemm256_edge_tiles_write_nothing_past_m(ops, dt, family):
     """The specialised epilogues store through buffer descriptors that end at the last valid row; the hardware must drop what an edge tile
     (M % 256 != 0) holds past it - for every flavour, the residual ones included (round 4 moved them to the same stores, and their
     residual loads and LayerNorm-partial stores to descriptors of their own).  Outputs are views of larger buffers here whose tail rows hold a
     sentinel: every flavour must leave them untouched, bit for bit.  (Row offsets travel in the bounds-checked vector offset; round 3's
     library, which carried them in the scalar offset, passes this test as well.)"""
-    M, N, K = 6160, 2048, 512            # 24 full tile rows + 16 valid rows in the last one; 200 tiles: one per workgroup
+    M, N, K = 6160, 2048, 512            # 24 full tile rows + 16 valid rows in the last one; 200 tiles: one per workgroup (384x256: 16 + 16 rows, 136 tiles)
     g = torch.Generator(device="cpu").manual_seed(11)
     a = torch.randn(M, K, generator=g).to(dt).to(DEV)
     w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
@@ -239,7 +253,7 @@ def test_gemm_families_are_bit_identical(ops, dt):
     g = torch.Generator(device="cpu").manual_seed(11)
     for (M, N, K) in ((50432, 768, 768), (30000, 2304, 768), (20000, 768, 3072)):
         ms = 197 * 3 + 5
-        assert lib.leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)) == b"gemm_tn_256x256x64_pp"
+        assert lib.leclip_gemm_kernel_name(M, N, K, ops.dtype_code(dt)) in (b"gemm_tn_384x256x32_pp", b"gemm_tn_256x256x64_pp")
         assert lib.leclip_gemm_kernel_name(ms, N, K, ops.dtype_code(dt)) == b"gemm_tn_128x128x64"
         a = torch.randn(M, K, generator=g).to(dt).to(DEV)
         w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
@@ -255,17 +269,63 @@ def test_gemm_families_are_bit_identical(ops, dt):
             (dict(bias=bias, residual=res), dict(bias=bias, residual=sres)),
             (dict(bias=bias, out_dtype=torch.float32), dict(bias=bias, out_dtype=torch.float32)),
         ]
-        for kb, ks in cases:
-            assert torch.equal(ops.gemm(a, w, **kb)[lo], ops.gemm(sa, w, **ks))
-        pb, ps = torch.zeros(N // 64, M, 2, device=DEV), torch.zeros(N // 64, ms, 2, device=DEV)
-        yb = ops.gemm_ln(a, w, bias, residual=res, stats_out=pb)
-        ys = ops.gemm_ln(sa, w, bias, residual=sres, stats_out=ps)
-        assert torch.equal(yb[lo], ys) and torch.equal(pb[:, lo], ps)
-        for act in (ops.ACT_NONE, ops.ACT_QUICKGELU):
-            yb = ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=act)
-            ys = ops.gemm_ln(sa, w, bias, ln_stats=sstats, ln_colsum=colsum, act=act)
-            assert torch.equal(yb[lo], ys)
+        for fam in (384, 256):      # the big call through each persistent family (round 5: leclip_set_gemm_family), the small one through 128x128
+            prev = ops.set_gemm_family(fam)
+            try:
+                big = [ops.gemm(a, w, **kb) for kb, _ in cases]
+                pb = torch.zeros(N // 64, M, 2, device=DEV)
+                big.append(ops.gemm_ln(a, w, bias, residual=res, stats_out=pb))
+                big += [ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=act) for act in (ops.ACT_NONE, ops.ACT_QUICKGELU)]
+            finally:
+                ops.set_gemm_family(prev)
+            small = [ops.gemm(sa, w, **ks) for _, ks in cases]
+            ps = torch.zeros(N // 64, ms, 2, device=DEV)
+            small.append(ops.gemm_ln(sa, w, bias, residual=sres, stats_out=ps))
+            small += [ops.gemm_ln(sa, w, bias, ln_stats=sstats, ln_colsum=colsum, act=act) for act in (ops.ACT_NONE, ops.ACT_QUICKGELU)]
+            for yb, ys in zip(big, small):
+                assert torch.equal(yb[lo], ys), fam
+            assert torch.equal(pb[:, lo], ps), fam
+            del big, small
         del a, w, res
+
+
+@pytest.mark.parametrize("family", [256, 384], indirect=True)
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_walk_order_never_changes_results(ops, dt, family):
+    """leclip_set_walk_order (ABI 8) only picks which rows a workgroup takes first: the reversed tile walk of both persistent GEMM families - ragged M,
+    even and odd K-tile counts (the 256x256 kernel pipelines across tiles only for even ones; its edge tile then runs FIRST), residual + partials and
+    fused-LayerNorm flavours - and of the many-heads attention kernel (T = 197, whose default is descending) must give the same bits as the ascending one."""
+    g = torch.Generator(device="cpu").manual_seed(23)
+    for (M, N, K) in ((50432 - 150, 768, 768), (40000 + 77, 768, 320)):
+        a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = torch.randn(M, N, generator=g).to(dt).to(DEV)
+        stats = torch.stack([torch.randn(M, generator=g) * 0.1, torch.rand(M, generator=g) + 0.5], dim=1).contiguous().to(DEV)
+        colsum = torch.randn(N, generator=g).to(DEV)
+        outs = {}
+        for order in (-1, 0, 1):
+            prev = ops.set_walk_order(order)
+            try:
+                part = torch.zeros(N // 64, M, 2, device=DEV)
+                outs[order] = (ops.gemm(a, w, bias), ops.gemm_ln(a, w, bias, residual=res, stats_out=part), part,
+                               ops.gemm_ln(a, w, bias, ln_stats=stats, ln_colsum=colsum, act=ops.ACT_QUICKGELU))
+            finally:
+                ops.set_walk_order(prev)
+        for order in (0, 1):
+            for x, y in zip(outs[-1], outs[order]):
+                assert torch.equal(x, y), (M, K, order)
+        del a, w, res, outs
+    if family == 256:
+        qkv = (torch.randn(90 * 197, 3 * 768, generator=g) * 0.8).to(dt).to(DEV)
+        ys = {}
+        for order in (-1, 0, 1):
+            prev = ops.set_walk_order(order)
+            try:
+                ys[order] = ops.attention(qkv, 90, 197, 12, False)
+            finally:
+                ops.set_walk_order(prev)
+        assert torch.equal(ys[-1], ys[0]) and torch.equal(ys[-1], ys[1])
 
 
 @pytest.mark.parametrize("dt", DTYPES)
