@@ -71,6 +71,9 @@ def main():
                          "ln_post(x[:, 0]) consumes (same logits bit for bit, 6 %% fewer FLOPs executed); its rate is reported beside the headline")
     ap.add_argument("--walk", default=None, choices=["default", "c_proj", "c_fc", "alternate"],
                     help="A/B: row walk-order policy of the block kernels (hip/engine.py _Walk; default: the engine's own, c_proj)")
+    ap.add_argument("--no-producer-merge", action="store_true", help="A/B: LayerNorm partials merged by a launch behind out-proj / c_proj instead of "
+                    "inside them (hip/engine.py producer_merge)")
+    ap.add_argument("--gemm-family", type=int, default=None, choices=[128, 256, 384], help="A/B: force a GEMM kernel family (leclip_set_gemm_family)")
     ap.add_argument("--image-dtype", default="compute", choices=["compute", "fp32"],
                     help="dtype the synthetic images are resident in when the timed region starts: the tower's compute dtype (default; SURVEY 8d: "
                          "'cast to bf16/fp16 for cfgs 2-5') or fp32 (the engine's patch-extraction kernel then casts inside the step)")
@@ -99,6 +102,9 @@ def main():
     from leclip_amd.trainers import CustomCLIP
 
     overrides = env_overrides()
+    if args.gemm_family is not None:
+        ops.set_gemm_family(args.gemm_family)
+        overrides = list(overrides) + [f"gemm_family={args.gemm_family}"]
     rank, world, local = parallel.init_from_env()
     if world != args.gpus:   # only reachable under a launcher whose rank count differs from --gpus (a bare invocation self-launches)
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE={world}")
@@ -135,6 +141,7 @@ def main():
         eng.cls_last_block = args.last_block == "class-token"
         if args.walk is not None:
             eng.walk = args.walk
+        eng.producer_merge = not args.no_producer_merge
         return cc
 
     def measure(cc, steps, warmup, profile_every):
@@ -350,6 +357,10 @@ def tune(args):
     from leclip_amd.registry import build_trainer
 
     overrides = env_overrides()
+    if args.gemm_family is not None:
+        from leclip_amd.hip import ops as _ops
+        _ops.set_gemm_family(args.gemm_family)
+        overrides = list(overrides) + [f"gemm_family={args.gemm_family}"]
     rank, world, _ = parallel.init_from_env()
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher's WORLD_SIZE={world}")

@@ -103,6 +103,16 @@ int leclip_gemm_ln_partials_fwd(const void* A, const void* W, const float* bias,
 /* (mean, rstd) per row: from the partial sums above (fixed summation order), or directly from rows of x. */
 int leclip_ln_stats_finalize_fwd(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps,
                                  void* stream);
+/* Residual GEMM that also finishes the LayerNorm statistics of its output rows (ABI 9, round 5):
+ *   Y = A W^T + bias + residual        (the residual-stream update of a block, clip/model.py:225-228: x + attention(...), x + mlp(...))
+ *   stats[m] = (mean, rstd) of row m of Y over its N columns, eps inside the rsqrt (what the NEXT LayerNorm's fp32 pass computes, clip/model.py:193-199)
+ * 16-bit operands.  partials_ws [N/64][M][2] fp32 receives the per-64-column block partials (sum, M2 about the block mean) as with
+ * leclip_gemm_ln_partials_fwd's stats_out.  On gemm_tn_384x256x32_pp the last of a 384-row block's workgroups to finish merges the block's partials
+ * inside the launch (tickets_ws: one uint32 per 384-row block, ZERO on entry and zero again when the launch has ended; null = never merge in
+ * the launch); otherwise the merge kernel runs behind the GEMM on the same stream.  Same arithmetic, same bits, as leclip_ln_stats_finalize_fwd. */
+int leclip_gemm_res_stats_fwd(const void* A, const void* W, const float* bias, const void* residual, void* Y, float* partials_ws, float* stats,
+                              unsigned* tickets_ws, float ln_eps, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldr, int64_t ldy,
+                              leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream);
 int leclip_row_stats_fwd(const void* x, float* stats, int64_t rows, int dim, int64_t ldx, float eps, leclip_dtype x_dtype,
                          void* stream);
 

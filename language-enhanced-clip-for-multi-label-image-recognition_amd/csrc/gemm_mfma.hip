@@ -311,6 +311,38 @@ extern "C" int leclip_gemm_bias_act_res_fwd(const void* A, const void* W, const 
 }
 
 int leclip_ln_stats_finalize_launch(const float* partials, float* stats, int64_t rows, int slots, int dim, float eps, hipStream_t s);
+bool leclip_gemm384_merges(int64_t M, int N);
+
+// Residual GEMM that also FINISHES the LayerNorm statistics of its output rows (round 5): Y = A W^T + bias + residual and stats[m] = (mean, rstd)
+// of row m of Y.  On the 384 x 256 kernel the row block's last-arriving workgroup merges the block partials in the launch itself; every other
+// dispatch writes the partials and this entry point launches the merge kernel behind the GEMM - the same bits either way (ln_merge_partials).
+extern "C" int leclip_gemm_res_stats_fwd(const void* A, const void* W, const float* bias, const void* residual, void* Y, float* partials_ws,
+                                         float* stats, unsigned* tickets_ws, float ln_eps, int64_t M, int N, int K, int64_t lda, int64_t ldw,
+                                         int64_t ldr, int64_t ldy, leclip_dtype ab_dtype, leclip_dtype res_dtype, leclip_dtype y_dtype, void* stream) {
+    if (!A || !W || !Y || !residual || !partials_ws || !stats || M <= 0 || N <= 0 || K <= 0 || lda < K || ldw < K || ldy < N || ldr < N || N % 64 != 0) {
+        leclip_set_error("gemm_res_stats: null pointer or inconsistent sizes (M=%lld N=%d K=%d)", (long long)M, N, K);
+        return LECLIP_E_INVALID;
+    }
+    if (ab_dtype == LECLIP_F32 || !dtype_ok(ab_dtype) || !dtype_ok(y_dtype) || !dtype_ok(res_dtype)) {
+        leclip_set_error("gemm_res_stats: 16-bit operands only");
+        return LECLIP_E_UNSUPPORTED;
+    }
+    if (((uintptr_t)partials_ws & 15) || ((uintptr_t)stats & 7) || ((uintptr_t)tickets_ws & 3)) {
+        leclip_set_error("gemm_res_stats: partials_ws 16-byte, stats 8-byte, tickets_ws 4-byte aligned");
+        return LECLIP_E_INVALID;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EpiParams e;
+    e.bias = bias; e.res = residual; e.out = Y; e.ldr = ldr; e.ldy = ldy;
+    e.res_dt = res_dtype; e.out_dt = y_dtype; e.act = LECLIP_ACT_NONE; e.rowmap_P = 0;
+    e.ln_stats = nullptr; e.ln_colsum = nullptr; e.ln_partials = nullptr; e.ln_slots = 0; e.ln_eps = 0.f;
+    e.stats_out = partials_ws; e.stats_slots = N / 64; e.stats_rows = M;
+    const bool merged = tickets_ws && leclip_gemm384_merges(M, N) && leclip_gemm384_eligible(M, N, K, lda, ldw, e, ab_dtype);
+    if (merged) { e.stats_merged = stats; e.stats_tickets = tickets_ws; e.stats_eps = ln_eps; }
+    const int rc = leclip_gemm_dispatch(A, W, M, N, K, lda, ldw, e, ab_dtype, s);
+    if (rc || merged) return rc;
+    return leclip_ln_stats_finalize_launch(partials_ws, stats, M, N / 64, N, ln_eps, s);
+}
 
 extern "C" int leclip_gemm_ln_fused_fwd(const void* A, const void* W, const float* bias, const float* ln_stats,
                                         const float* ln_colsum, const void* residual, void* Y, float* stats_out, int64_t M,

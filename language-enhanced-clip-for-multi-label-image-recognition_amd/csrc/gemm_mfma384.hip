@@ -414,7 +414,11 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
 #pragma unroll
                 for (int pp = 0; pp < 4; ++pp)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o[pp]), orsrc, voff + (q * 16 + pp * 4) * ldb, 0, 0);
+#ifdef LECLIP_G384_ABL_NOSTATS   // timing-only A/B build: no partials (out-proj 75.2 -> 72.8 us, c_proj 229.8 -> 227.2: profiles/r05_g384_notes.txt)
+                if constexpr (false) {
+#else
                 if constexpr (STATS == 1) {
+#endif
                     // LayerNorm partials of the stored values: the 8 lanes of a (row, 64-column slot) hold its pair; lane cc < 4 of each group stores
                     // the pair of pass cc's row - one store per strip: two 128-byte runs (16 rows x 8 bytes) in the wave's two slots
                     f32x2 sel = row_block_stats(o[0]);
@@ -426,7 +430,58 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                     }
                     const int r = q * 16 + cc * 4 + crow;
                     const int svoff = (cc < 4 && r < rows_ok) ? (int)((((lane_q >> 3) & 1) * e.stats_rows + r) * 8) : 0x7ff00000;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, sel), srsrc, svoff, 0, 0);
+                    // (write-through, sc1: the row block's last-arriving workgroup may read these pairs in this launch - see the merge below)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(i32x2, sel), srsrc, svoff, 0, 16);
+                }
+            }
+        }
+        if constexpr (STATS == 1) {
+            if (e.stats_merged) {   // (uniform)
+                // In-producer LayerNorm merge.  Hand-off by MI355X_MICROARCH.md's measured form: every byte stored sc1 and drained by its storing
+                // wave (vmcnt(0)), a workgroup barrier, ONE lane's returning agent-scope add on the row block's counter; the workgroup whose add
+                // comes last (told by the returned value - nobody waits or spins) reads every pair with sc1 loads.  Both barriers are executed
+                // by all eight waves (the two wave groups are aligned here).
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                unsigned* flag = (unsigned*)(smem + CST_OFF + 2048);      // (the (mean, rstd) region: unused by the residual flavours)
+                const int tmb = (int)(em0 / TM);
+                if (wave == 0) {
+                    unsigned old = 0;
+                    if (lane == 0) old = __hip_atomic_fetch_add(e.stats_tickets + tmb, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    old = __builtin_amdgcn_readfirstlane(old);
+                    const unsigned last = old == (unsigned)(g.tiles_n - 1) ? 1u : 0u;
+                    if (lane == 0) {
+                        *flag = last;
+                        if (last) __hip_atomic_store(e.stats_tickets + tmb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                if (*(volatile unsigned*)flag) {
+                    // 384 rows, 48 per wave, one per lane: the row's pairs slot by slot (consecutive lanes read consecutive pairs of a slot)
+                    int lm = lane_e;
+                    asm volatile("" : "+v"(lm));
+                    const int64_t leftb = g.M - em0;
+                    const int rows_b = leftb >= TM ? TM : (int)leftb;
+                    const int row = wave * 48 + lm;
+                    const bool act_row = lm < 48 && row < rows_b;
+                    const int slots = e.stats_slots;
+                    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(
+                        uniform_ptr384((const char*)e.stats_out), 0, __builtin_amdgcn_readfirstlane((int)((unsigned)slots * (unsigned)e.stats_rows * 8u)), 0x00020000);
+                    const int pv = act_row ? (int)((em0 + row) * 8) : 0x7ff00000;
+                    const int sstep = __builtin_amdgcn_readfirstlane((int)(e.stats_rows * 8));
+                    f32x4 v[LN_MERGE_MAXV];
+#pragma unroll
+                    for (int i = 0; i < LN_MERGE_MAXV; ++i) {
+                        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (2 * i < slots) {
+                            const i32x2 a = __builtin_amdgcn_raw_buffer_load_b64(prsrc, pv, (2 * i) * sstep, 16);
+                            const i32x2 b = __builtin_amdgcn_raw_buffer_load_b64(prsrc, pv, (2 * i + 1) * sstep, 16);
+                            v[i][0] = __int_as_float(a[0]); v[i][1] = __int_as_float(a[1]); v[i][2] = __int_as_float(b[0]); v[i][3] = __int_as_float(b[1]);
+                        }
+                    }
+                    const f32x2 mr = ln_merge_partials(v, slots, g.N, e.stats_eps);
+                    if (act_row) *(f32x2*)(e.stats_merged + 2 * (em0 + row)) = mr;
                 }
             }
         }
@@ -468,6 +523,9 @@ bool leclip_gemm384_shape(int64_t M, int N, int K) {
     if (fam >= 0) return fam == 384;
     return ((M + TM - 1) / TM) * (N / TN) >= 160;
 }
+
+// In-producer LayerNorm merge: the partials' slots must fit ln_merge_partials (an even count <= 16) and a block's pair offsets 32 bits.
+bool leclip_gemm384_merges(int64_t M, int N) { return (N / 64) % 2 == 0 && N / 64 <= 2 * LN_MERGE_MAXV && (int64_t)(N / 64) * M * 8 < 0x7ff00000LL; }
 
 bool leclip_gemm384_eligible(int64_t M, int N, int K, int64_t lda, int64_t ldw, const EpiParams& e, int ab_dtype) {
     if (!leclip_gemm384_shape(M, N, K)) return false;

@@ -137,6 +137,12 @@ struct EpiParams {
     float* stats_out;        // [stats_slots][stats_rows][2] or null
     int stats_slots;
     int64_t stats_rows;      // rows of the partials tensor (= M of the producing GEMM)
+    // Round 5, in-producer merge (gemm_tn_384x256x32_pp only): the workgroup whose ticket on a 384-row block's counter comes last merges the
+    // block's partials (ln_merge_partials: the finalize kernel's arithmetic, same bits) into stats_merged [M][2] = (mean, rstd) - no merge
+    // launch between producer and consumer.  stats_tickets: one counter per row block, zero on entry, zero again when the launch has ended.
+    float* stats_merged = nullptr;
+    unsigned* stats_tickets = nullptr;
+    float stats_eps = 0.f;
 };
 
 typedef __attribute__((ext_vector_type(4))) int i32x4;

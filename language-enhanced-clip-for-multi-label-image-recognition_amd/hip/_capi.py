@@ -44,6 +44,8 @@ SIGNATURES = {
                                             c_void_p, c_void_p, c_int64, c_int, c_int, c_int64, c_int64, c_int64, c_int64, c_int, c_int,
                                             c_int, c_int, c_void_p]),
     "leclip_ln_stats_finalize_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_float, c_void_p]),
+    "leclip_gemm_res_stats_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_float, c_int64, c_int, c_int,
+                                          c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_int, c_void_p]),
     "leclip_row_stats_fwd": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_float, c_int, c_void_p]),
     "leclip_patch_embed_workspace_bytes": (c_int64, [c_int64, c_int, c_int, c_int]),
     "leclip_patch_embed_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,

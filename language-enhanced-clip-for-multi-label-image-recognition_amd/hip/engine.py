@@ -85,6 +85,8 @@ class _Workspace:
         self.stats = torch.empty((rows, 2), dtype=torch.float32, device=device)
         # slot-major [d/64][rows][2]: the rows a wave finishes together are contiguous bytes of one slot (one full-line store per pass)
         self.partials = torch.empty((d // 64, rows, 2), dtype=torch.float32, device=device)
+        # in-producer LayerNorm merge (ops.gemm_res_stats): one arrival counter per 384-row block, zero between launches
+        self.tickets = torch.zeros(((rows + 383) // 384 + 1,), dtype=torch.int32, device=device)
         if batch > 0:   # image tower: the last block's class-token rows (run_blocks, ``cls_last``)
             self.cls_x = torch.empty((batch, d), dtype=dtype, device=device)
             self.cls_u = torch.empty((batch, 4 * d), dtype=dtype, device=device)
@@ -126,7 +128,7 @@ class _Walk:
 
 def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int, heads: int, causal: bool,
                taps: Optional[dict] = None, fuse_ln: Optional[bool] = None, have_partials: bool = False,
-               cls_last: bool = False, walk: str = "default") -> torch.Tensor:
+               cls_last: bool = False, walk: str = "default", producer_merge: bool = True) -> torch.Tensor:
     """x [B*T, d] (updated in place) through the residual attention blocks (clip/model.py:225-228).
 
     16-bit modes fuse both LayerNorms of a block into the GEMM that consumes them (``fuse_ln``): the producing GEMM's
@@ -152,7 +154,10 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
         else:
             ops.row_stats(x, out=ws.stats)
             src = dict(ln_stats=ws.stats)
-        after = dict(ln_partials=ws.partials, ln_stats_ws=ws.stats)
+        # Round 5: out-proj / c_proj FINISH the statistics of the rows they write (ops.gemm_res_stats: in the launch itself on the 384 x 256
+        # kernel, by the merge kernel behind the GEMM otherwise) - the consumer takes (mean, rstd) as they are, no merge launch in front of it
+        after = dict(ln_stats=ws.stats)
+        tickets = ws.tickets if producer_merge else None     # (None: always the merge launch - A/B, bench.py --no-producer-merge)
         last = len(blocks) - 1
         walk = _Walk(walk)
         try:   # (an exception mid-block must not leave the calling thread's walk-order hint set for later launches)
@@ -161,8 +166,13 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
                     walk.done()
                     x_c = x.view(batch, tokens * d)[:, :d]             # class rows in place: [B, d] with row stride T*d
                     cls = dict(ln_partials=ws.cls_partials, ln_stats_ws=ws.cls_stats)
-                    if "ln_partials" in src:
-                        # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only
+                    if i > 0:
+                        # keys and values of every token (the k|v rows of in_proj: N = 2d), queries of the class rows only (their statistics:
+                        # the class rows of the (mean, rstd) the previous block's c_proj finished)
+                        ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
+                        ops.gather_rows(ws.stats, ws.cls_index, out=ws.cls_stats)
+                        ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], ln_stats=ws.cls_stats)
+                    elif "ln_partials" in src:
                         ops.gemm_ln(x, p.wf_qkv[d:], p.cb_qkv[d:], ln_colsum=p.cs_qkv[d:], out=ws.qkv[:, d:], **src)
                         ops.gather_rows(ws.partials.view(-1, 2), ws.cls_pair_index, out=ws.cls_partials.view(-1, 2))
                         ops.gemm_ln(x_c, p.wf_qkv[:d], p.cb_qkv[:d], ln_colsum=p.cs_qkv[:d], out=ws.qkv.view(batch, tokens * 3 * d)[:, :d], **cls)
@@ -179,12 +189,12 @@ def run_blocks(x: torch.Tensor, blocks, ws: _Workspace, batch: int, tokens: int,
                 walk.set("attention")
                 ops.attention(ws.qkv, batch, tokens, heads, causal, out=ws.ctx)
                 walk.set("out_proj")
-                ops.gemm_ln(ws.ctx, p.w_o, p.b_o, residual=x, stats_out=ws.partials, out=x)
+                ops.gemm_res_stats(ws.ctx, p.w_o, p.b_o, residual=x, partials=ws.partials, stats_out=ws.stats, tickets=tickets, out=x)
                 walk.set("c_fc")
                 ops.gemm_ln(x, p.wf_fc, p.cb_fc, ln_colsum=p.cs_fc, act=ACT_QUICKGELU, out=ws.u, **after)
                 walk.set("c_proj")
                 if i < last:
-                    ops.gemm_ln(ws.u, p.w_pr, p.b_pr, residual=x, stats_out=ws.partials, out=x)
+                    ops.gemm_res_stats(ws.u, p.w_pr, p.b_pr, residual=x, partials=ws.partials, stats_out=ws.stats, tickets=tickets, out=x)
                     src = after
                 else:
                     ops.gemm(ws.u, p.w_pr, p.b_pr, residual=x, out=x)
@@ -325,6 +335,8 @@ class VisionEngine:
         # walk-order policy of the block kernels (run_blocks, _Walk): which rows a kernel takes first - same bits either way.  "default":
         # with the batch as two stream parts (the product schedule) no policy measured a gain (profiles/r04_walk_order.txt)
         self.walk = "default"
+        # out-proj / c_proj merge their LayerNorm partials inside the launch (384 x 256 kernel; False: a merge launch behind every one of them)
+        self.producer_merge = True
 
     def _parts(self, image: torch.Tensor):
         """Row ranges of the stream parts, or None when the batch runs as one piece."""
@@ -403,7 +415,7 @@ class VisionEngine:
         cls_last = (cls_only and self.cls_last_block and taps is None and self.dtype != torch.float32 and self.width % 64 == 0
                     and self.width <= 1024 and self.proj.shape[1] % 16 == 0)     # (the conditions of the fused path and of the tail kernel)
         rows = run_blocks(x, self.blocks, ws, batch, self.tokens, self.heads, False, taps, have_partials=have_partials, cls_last=cls_last,
-                          walk=self.walk)
+                          walk=self.walk, producer_merge=self.producer_merge)
         if cls_last:
             return rows, batch, None, self.width
         return x, batch, cls_rows, self.tokens * self.width

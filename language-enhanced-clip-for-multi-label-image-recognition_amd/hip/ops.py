@@ -336,6 +336,34 @@ def gemm_ln(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = Non
     return out
 
 
+def gemm_res_stats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor, partials: torch.Tensor,
+                   stats_out: torch.Tensor, tickets: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, eps: float = 1e-5) -> torch.Tensor:
+    """out = a @ w.T + bias + residual and stats_out [M, 2] = (mean, rstd) of out's rows (leclip_gemm_res_stats_fwd): the residual-stream update
+    of a block with the next LayerNorm's statistics finished by the producer - on the 384 x 256 kernel inside the launch (``tickets``: int32 zeros,
+    one per 384-row block, left zero), otherwise by the merge kernel behind it.  ``partials`` [N/64, M, 2] is scratch (it keeps the block partials)."""
+    m, k, lda = _rows2d(a, "a")
+    n, kw, ldw = _rows2d(w, "w")
+    if k != kw or a.dtype != w.dtype:
+        raise ValueError(f"gemm_res_stats: a [.., {k}] {a.dtype} vs w [{n}, {kw}] {w.dtype}")
+    if out is None:
+        out = torch.empty(a.shape[:-1] + (n,), dtype=a.dtype, device=a.device)
+    _, _, ldy = _rows2d(out, "out")
+    _, _, ldr = _rows2d(residual, "residual")
+    for name, t, shape in (("partials", partials, (n // 64, m, 2)), ("stats_out", stats_out, (m, 2)), ("bias", bias, (n,))):
+        if t is not None:
+            _dev(t, name)
+            assert t.dtype == torch.float32 and tuple(t.shape) == shape and t.is_contiguous(), (name, tuple(t.shape), shape)
+    if tickets is not None:
+        _dev(tickets, "tickets")
+        assert tickets.dtype == torch.int32 and tickets.is_contiguous() and tickets.numel() >= (m + 383) // 384
+    nbytes = (m * k + n * k) * a.element_size() + 2 * m * n * out.element_size()
+    with _Timed("gemm", 2 * m * n * k, nbytes, f"M{m} N{n} K{k}"):
+        _capi.check(_capi.load().leclip_gemm_res_stats_fwd(_ptr(a), _ptr(w), _ptr(bias), _ptr(residual), _ptr(out), _ptr(partials), _ptr(stats_out),
+                                                           _ptr(tickets), eps, m, n, k, lda, ldw, ldr, ldy, dtype_code(a.dtype),
+                                                           dtype_code(residual.dtype), dtype_code(out.dtype), _stream()), "gemm_res_stats")
+    return out
+
+
 def ln_stats_finalize(partials: torch.Tensor, dim: int, eps: float = 1e-5, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _dev(partials, "partials")
     assert partials.dtype == torch.float32 and partials.dim() == 3 and partials.shape[2] == 2 and partials.is_contiguous()

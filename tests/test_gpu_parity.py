@@ -289,6 +289,40 @@ def test_gemm_families_are_bit_identical(ops, dt):
         del a, w, res
 
 
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+def test_gemm_res_stats_merges_in_the_producer(ops, dt):
+    """leclip_gemm_res_stats_fwd (round 5): the residual GEMM finishes the (mean, rstd) of its output rows - on the 384 x 256 kernel inside the
+    launch (the 384-row block's last-arriving workgroup merges the three N-tiles' partials: write-through stores, a returning ticket, sc1 loads),
+    elsewhere by the merge kernel behind the GEMM.  Output, partials and statistics must equal the two-launch path bit for bit: full and ragged M,
+    every 384-row block, repeated launches on the same ticket words (they must come back to zero), other work in between (the hand-off must
+    not depend on what the caches hold), and a small M that takes the 128 x 128 kernel + merge launch."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for (M, N, K) in ((50432, 768, 768), (25216, 768, 3072), (25216 - 300, 768, 768), (4000, 1024, 1024), (1576, 768, 768)):
+        a = torch.randn(M, K, generator=g).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.05).to(dt).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        res = (torch.randn(M, N, generator=g) + 3.0).to(dt).to(DEV)
+        part_ref = torch.zeros(N // 64, M, 2, device=DEV)
+        y_ref = ops.gemm_ln(a, w, bias, residual=res, stats_out=part_ref)
+        st_ref = ops.ln_stats_finalize(part_ref, N)
+        tickets = torch.zeros((M + 383) // 384, dtype=torch.int32, device=DEV)
+        junk = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+        for rep in range(6):
+            part = torch.full((N // 64, M, 2), float("nan"), device=DEV)
+            st = torch.full((M, 2), float("nan"), device=DEV)
+            if rep % 2:
+                junk.fill_(rep)                              # other traffic between the launches
+                _ = st_ref.sum(); _ = part_ref[:, ::7].sum()  # and the reference lines warm in the caches
+            y = ops.gemm_res_stats(a, w, bias, res, part, st, tickets)
+            assert torch.equal(y, y_ref) and torch.equal(part, part_ref), (M, K, rep)
+            assert torch.equal(st, st_ref), (M, K, rep, int((st != st_ref).sum()))
+            assert int(tickets.abs().sum()) == 0, "ticket counters must return to zero"
+        st = torch.full((M, 2), float("nan"), device=DEV)
+        ops.gemm_res_stats(a, w, bias, res, torch.zeros_like(part_ref), st, None)     # no tickets: GEMM + merge launch
+        assert torch.equal(st, st_ref)
+        del a, w, res
+
+
 @pytest.mark.parametrize("family", [256, 384], indirect=True)
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
 def test_walk_order_never_changes_results(ops, dt, family):
