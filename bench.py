@@ -71,13 +71,15 @@ def main():
                          "ln_post(x[:, 0]) consumes (same logits bit for bit, 6 %% fewer FLOPs executed); its rate is reported beside the headline")
     ap.add_argument("--walk", default=None, choices=["default", "c_proj", "c_fc", "alternate"],
                     help="A/B: row walk-order policy of the block kernels (hip/engine.py _Walk; default: the engine's own, c_proj)")
+    ap.add_argument("--no-companions", action="store_true", help="skip the cfg5 (ViT-L/14@336) and cfg3 (tuning step) companion child runs of the default run")
+    ap.add_argument("--raw-batch", type=int, default=8, help="--mode multicrop: raw 640x480 images per step (305 windows each)")
     ap.add_argument("--no-producer-merge", action="store_true", help="A/B: LayerNorm partials merged by a launch behind out-proj / c_proj instead of "
                     "inside them (hip/engine.py producer_merge)")
     ap.add_argument("--gemm-family", type=int, default=None, choices=[128, 256, 384], help="A/B: force a GEMM kernel family (leclip_set_gemm_family)")
     ap.add_argument("--image-dtype", default="compute", choices=["compute", "fp32"],
                     help="dtype the synthetic images are resident in when the timed region starts: the tower's compute dtype (default; SURVEY 8d: "
                          "'cast to bf16/fp16 for cfgs 2-5') or fp32 (the engine's patch-extraction kernel then casts inside the step)")
-    ap.add_argument("--mode", default="score", choices=["score", "tune"],
+    ap.add_argument("--mode", default="score", choices=["score", "tune", "multicrop"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
     ap.add_argument("--tune-model", default="CustomCLIP", choices=["CustomCLIP", "DenseCLIP"],
@@ -91,6 +93,8 @@ def main():
         return self_launch(args)
     if args.mode == "tune":
         return tune(args)
+    if args.mode == "multicrop":
+        return multicrop(args)
 
     import torch
     import torch.distributed as dist
@@ -144,15 +148,16 @@ def main():
         eng.producer_merge = not args.no_producer_merge
         return cc
 
-    def measure(cc, steps, warmup, profile_every):
+    def measure(cc, steps, warmup, profile_every, image_dtype=None):
         """W untimed + exactly K timed steps of the hot path, bracketed by barrier + synchronize; max over ranks."""
+        image_dtype = image_dtype or args.image_dtype
         eng = cc.image_encoder.engine(dev)
         run_streams, run_split = eng.streams, eng.split_sizes
         scorer = parallel.ShardedScorer(lambda x: cc(x, if_test=True)[0])
         # SURVEY section 8d: the synthetic images are "cast to bf16/fp16 for cfgs 2-5" - input preparation, done once here, outside the timed
         # region (inputs resident in HBM in the dtype the tower computes in; the reference's own encode_image casts with image.type(self.dtype),
         # clip/model.py:377: same rounding).  The engine takes fp32 images as well (a patch-extraction kernel then does the cast).
-        images_dt = images.to(eng.dtype) if args.image_dtype == "compute" else images
+        images_dt = images.to(eng.dtype) if image_dtype == "compute" else images
         step = lambda: scorer.score_local(images_dt)
         with torch.no_grad():
             cc.class_text_features()          # text tower runs once; its features are cached for inference (SURVEY §8d)
@@ -287,6 +292,15 @@ def main():
         result["class_token_last_block"] = {"value": B * args.steps / dt3, "unit": "img/s", "ms_per_step": dt3 / args.steps * 1e3, "steps": args.steps,
                                             "flops_per_image_executed": fpi - skipped,
                                             "note": "engine default outside this benchmark; logits bit-identical to the headline run's"}
+    # Companion measurement (VERDICT r4 task 4a): the hand-over the reference actually has - fp32 images from parse_batch_test, cast inside
+    # encode_image (clip/model.py:376-377).  Same engine; an fp32 batch goes through the patch-extraction kernel (which does the cast) instead of the
+    # im2col-free gather of the 16-bit path.  One sampled step gives the patch path's own time.
+    if world == 1 and args.image_dtype == "compute" and args.dtype != "fp32" and not args.no_second_dtype:
+        dt4, prof4, _ = measure(cc, args.steps, max(2, args.warmup // 2), args.steps, image_dtype="fp32")
+        pe = [e0.elapsed_time(e1) * 1e3 for name, _, _, e0, e1, _ in prof4 if name == "patch_embed"]
+        result["fp32_images"] = {"value": B * args.steps / dt4, "unit": "img/s", "ms_per_step": dt4 / args.steps * 1e3, "steps": args.steps,
+                                 "patch_embed_us": sum(pe) / max(len(pe), 1), "patch_embed_us_16bit_images": kernels.get("patch_embed", {}).get("avg_us"),
+                                 "note": "fp32 NCHW images resident in HBM, cast inside the timed region by the patch-extraction kernel"}
     # Companion measurement: BASELINE configs[1] words the config as bf16.  Same kernels, same rate, but bf16 misses the
     # north star's +-0.2 mAP clause, so it is not the headline: its rate and mAP sit beside the fp16 line.
     if world == 1 and args.dtype == "fp16" and not args.no_second_dtype:
@@ -300,11 +314,34 @@ def main():
             comp["mAP"] = score_against(ref_pack, cc2, arch, dev, "bf16")
             comp["mAP"]["accuracy_gate"] = accuracy_gate(comp["mAP"], "bf16")
         result["bf16"] = comp
+        del cc2
+    # Companion measurements (VERDICT r4 task 6): BASELINE configs[4] (ViT-L/14@336 fp16, one GPU's share B = 128) and configs[2] (prompt-tuning step,
+    # B = 512) as CHILD processes of this run, after the headline's timed region - each prints its own line (with its own roofline block), of which
+    # the key figures are kept here so that the driver's record carries them.
+    if world == 1 and not args.no_second_dtype and not args.no_companions and args.arch == "ViT-B/16" and args.batch == 256:
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        result["cfg5_vitl"] = companion_run(["--arch", "ViT-L/14@336px", "--batch", "128", "--steps", "10", "--warmup", "3", "--no-cpu-baseline",
+                                             "--no-second-dtype"], ("value", "unit", "ms_per_step", "steps", "dtype", "end_to_end_mfma_frac", "roofline", "gemm_shapes", "kernels"))
+        result["cfg3_tune"] = companion_run(["--mode", "tune", "--dtype", "bf16", "--steps", "10", "--warmup", "3"],
+                                            ("value", "unit", "ms_per_step", "steps", "dtype", "roofline", "config"))
     if rank == 0:
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def companion_run(flags, keep):
+    """One more configuration of this script as a child process (never an exec: the parent has initialised the GPU); its JSON line, cut to ``keep``."""
+    import subprocess
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__)] + flags, capture_output=True, text=True, timeout=420)
+        line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {k: d[k] for k in keep if k in d}
+    except Exception as exc:      # the headline line must not die of a companion
+        return {"error": repr(exc)[:300]}
 
 
 def launcher_argv(n_gpus, bench_args, port):
@@ -344,6 +381,104 @@ def env_overrides():
         print(f"bench.py: refusing to run with kernel diagnostic switches in the environment: {bad}", file=sys.stderr)
         sys.exit(2)
     return [f"{k}={os.environ[k]}" for k in found]
+
+
+def multicrop(args):
+    """Secondary measurement (VERDICT r4 task 5): the reference's REAL inference path - SURVEY row N2; trainers/Caption_distill_double.py:637-676 with
+    dassl/data/data_manager.py:311-492.  A step = B raw uint8 640 x 480 images -> the full image + the 304 sliding windows of scales (2, 3, 4) (the
+    shipped run_eval.sh) through the Pillow-exact device resampler (crop_resize_kernel: bicubic Resize, CenterCrop, ToTensor, Normalize) ->
+    the hot path (image tower + cosine logits) in chunks of --batch crops -> window aggregation (max / min, threshold 0.3) -> 1.4 s_ag + global.
+    Reports images/s and crops/s, and a roofline block for crop_resize_kernel: algorithmic bytes = the windows' source footprints + 301 KB of
+    16-bit output per crop, against the HBM peak (the kernel computes its coefficient tables in fp64 per output tile: how far below the byte
+    roof it runs says how much of it is arithmetic)."""
+    import numpy as np
+    import torch
+    from leclip_amd import synth
+    from leclip_amd.clip import build_model, convert_weights
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.datasets import coco_object_categories
+    from leclip_amd.hip import ops
+    from leclip_amd.multicrop import MultiCropper
+    from leclip_amd.trainers import CustomCLIP
+
+    overrides = env_overrides()
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    arch = synth.ARCHS[args.arch]
+    DT = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+    sd = synth.make_state_dict(arch, seed=0, dist="cond")
+    model = build_model(sd).float()
+    if DT[args.dtype] != torch.float32:
+        convert_weights(model, DT[args.dtype])
+    cfg = get_cfg_default()
+    cfg.INPUT.SIZE = (arch.image_resolution, arch.image_resolution)
+    cc = CustomCLIP(cfg, coco_object_categories, model)
+    with torch.no_grad():
+        cc.prompt_learner.ctx.copy_(torch.from_numpy(synth.make_ctx(16, arch.transformer_width, seed=0)))
+    cc = cc.to(dev).eval()
+    eng = cc.image_encoder.engine(dev)
+    H, W, scales = 480, 640, (2, 3, 4)
+    Braw, chunk = args.raw_batch, args.batch
+    rng = np.random.default_rng(1234)
+    raw = torch.from_numpy(rng.integers(0, 256, size=(Braw, 3, H, W), dtype=np.uint8)).to(dev)
+    cropper = MultiCropper(arch.image_resolution, scales, dtype=eng.dtype)
+    win, counts = cropper.windows(H, W, dev)
+    nw = int(win.shape[0])                                    # 1 + 304
+    wnp = win.cpu().numpy()
+    src_bytes = int((wnp[:, 2].astype(np.int64) * wnp[:, 3]).sum()) * 3
+    out_bytes = nw * 3 * arch.image_resolution ** 2 * (2 if eng.dtype != torch.float32 else 4)
+    ev = []
+
+    def step(timed):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if timed:
+            e[0].record()
+        crops = ops.crop_resize(raw, win, arch.image_resolution, cropper.mean, cropper.std, eng.dtype)     # [B, 305, 3, S, S]
+        if timed:
+            e[1].record()
+        flat = crops.view(Braw * nw, 3, arch.image_resolution, arch.image_resolution)
+        logits = torch.cat([cc(flat[i:i + chunk], if_test=True)[0].float() for i in range(0, Braw * nw, chunk)]).view(Braw, nw, -1)
+        if timed:
+            e[2].record()
+        out = ops.window_aggregate(logits[:, 0].contiguous(), logits[:, 1:].contiguous(), threshold=0.3, weight=1.4)
+        if timed:
+            e[3].record()
+            ev.append(e)
+        return out
+
+    with torch.no_grad():
+        cc.class_text_features()
+        for _ in range(args.warmup):
+            out = step(False)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            out = step(i % 5 == 2)           # events on every fifth step
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert out.shape == (Braw, 80) and bool(torch.isfinite(out).all())
+    crop_us = sum(a[0].elapsed_time(a[1]) for a in ev) / len(ev) * 1e3
+    tower_us = sum(a[1].elapsed_time(a[2]) for a in ev) / len(ev) * 1e3
+    agg_us = sum(a[2].elapsed_time(a[3]) for a in ev) / len(ev) * 1e3
+    alg = Braw * (src_bytes + out_bytes)
+    crops_s = Braw * nw * args.steps / dt
+    result = {
+        "metric": f"images/sec (multi-crop inference: {nw} windows per {W}x{H} image, scales {scales})", "value": Braw * args.steps / dt, "unit": "img/s",
+        "crops_per_s": crops_s, "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic (uniform random uint8 pixels)",
+        "config": {"workload": f"{args.arch}: {Braw} raw {W}x{H} uint8 images per step -> {nw} crops each (crop_resize_kernel) -> image tower + cosine logits in "
+                               f"chunks of {chunk} -> window_aggregate (SURVEY N2; reference CDD.py:637-676)", "crops_per_step": Braw * nw, "windows_per_scale": counts},
+        "roofline": {"bound": "hbm", "kernel": "crop_resize_kernel", "achieved": alg / crop_us * 1e-3, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": alg / crop_us * 1e-3 / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_launch": alg, "avg_launch_us": crop_us,
+                     "source_footprint_bytes_per_image": src_bytes, "output_bytes_per_image": out_bytes,
+                     "note": "per output tile the kernel rebuilds Pillow's bicubic coefficient tables in IEEE double: below the byte roof = arithmetic"},
+        "kernels": {"crop_resize": {"avg_us": crop_us, "crops_per_s_alone": Braw * nw / crop_us * 1e6}, "tower_and_logits": {"avg_us": tower_us, "crops_per_s_alone": Braw * nw / tower_us * 1e6},
+                    "window_aggregate": {"avg_us": agg_us}},
+        "resampler_keeps_up": Braw * nw / crop_us * 1e6 >= 0.9 * (Braw * nw / tower_us * 1e6),
+        "env_overrides": overrides,
+    }
+    print(json.dumps(result))
+    return 0
 
 
 def tune(args):
@@ -459,7 +594,8 @@ def tune(args):
 def _tune_roofline(prof):
     """roofline block of a --mode tune line: the MFMA GEMM family of ONE sampled step of the timed region (forward and backward GEMMs of
     the text tower - M = 80 x 77 = 6 160 rows per prompt set - and, on image batches, the frozen image tower's), from HIP events around every
-    launch; per launch shape underneath.  traffic: null (no counter pass of the tuning step is committed)."""
+    launch; per launch shape underneath.  traffic: HBM bytes per GEMM launch from the committed counter passes of this command
+    (profiles/r*_tune_pmc_summary.json, collected by profiles/collect.sh extra), or null when there is none."""
     fam, shapes = [0.0, 0, 0], {}
     for name, fl, nb, e0, e1, shape in prof:
         if name != "gemm":
@@ -472,19 +608,20 @@ def _tune_roofline(prof):
         return None
     tf = fam[1] / fam[0] * 1e-12
     top = sorted(shapes.items(), key=lambda kv: -kv[1][0])[:8]
-    return {"bound": "mfma", "kernel": "gemm_tn_256x256x64_pp / gemm_tn_128x128x64 (by M)", "achieved": tf, "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf / PEAK_MFMA_TFLOPS, "traffic": None, "launches": fam[2], "avg_launch_us": fam[0] / fam[2] * 1e6,
+    traffic, traffic_src = _pmc_traffic("tune_pmc_summary.json")
+    return {"bound": "mfma", "kernel": "gemm_tn_384x256x32_pp / gemm_tn_256x256x64_pp / gemm_tn_128x128x64 (by tile count)", "achieved": tf, "peak": PEAK_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": tf / PEAK_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_src, "launches": fam[2], "avg_launch_us": fam[0] / fam[2] * 1e6,
             "gemm_ms_of_step": fam[0] * 1e3, "measured_on": "one sampled step inside the timed region, batch as one part",
             "gemm_shapes": {k: {"launches": v[2], "avg_us": v[0] / v[2] * 1e6, "tflops": v[1] / v[0] * 1e-12,
                                 "mfma_frac": v[1] / v[0] * 1e-12 / PEAK_MFMA_TFLOPS} for k, v in top}}
 
 
-def _pmc_traffic():
+def _pmc_traffic(suffix="pmc_summary.json"):
     """HBM bytes per GEMM launch.  NOT measured by this process: rocprofv3 --pmc cannot run inside the timed run, so the
     figure is read from the committed summary of the separate counter passes over this same command
-    (profiles/*_pmc_summary.json, newest round), and the source file is named next to it."""
+    (profiles/r<NN>_pmc_summary.json, newest round; r<NN>_tune_pmc_summary.json for the tuning step), and the source file is named next to it."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + suffix)))
     if not files:
         return None, None
     try:
@@ -520,6 +657,7 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    affinity = cores          # what this process may run on (printed beside the count used)
     cores = min(cores, 16)   # the GPU box gives one GPU's job a 16-core share; more threads only oversubscribe
     torch.set_num_threads(cores)
     cb = 32
@@ -551,7 +689,7 @@ def cpu_baseline(args, arch, sd, cc, ctx, dev):
             t0 = time.perf_counter()
             co.cosine_logits(co.encode_image(imgs8, sd), txt, 4.0)
             best8 = min(best8, time.perf_counter() - t0)
-    base = {"value": n * cb / spent, "unit": "img/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
+    base = {"value": n * cb / spent, "unit": "img/s", "cores": cores, "affinity_cores": affinity, "host_cores": os.cpu_count(), "kind": "port", "cpu_model": _cpu_model(),
             "b8_value": 8 / best8, "b8_note": "BASELINE configs[0] (B=8): best of 3 after one warm-up, same oracle, same threads",
             "sample": f"{n} batches of {cb} images, fp32 torch-CPU oracle forward + logits, {spent:.1f} s of CPU work, "
                       f"torch {torch.__version__}, {cores} threads"}

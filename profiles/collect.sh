@@ -4,7 +4,7 @@
 # ViT-L/14@336 large-model point (BASELINE configs[4], one GPU's share B=128) and the prompt-tuning step (configs[2]).
 # Raw output under gpurun_out/prof_<tag>/ ; `python profiles/summarize.py <tag>` turns it into the committed files.
 set -o pipefail
-TAG=${1:-r04}
+TAG=${1:-r05}
 PART=${2:-all}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -27,7 +27,7 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES S
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_grbm -- $CMD > $OUT/pmc_grbm.log 2>&1 || exit 1
 echo pmc sq done
 cd $R
-timeout -k 10 300 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
+timeout -k 10 500 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err || exit 1
 echo main collected
 if [ "$PART" = main ]; then exit 0; fi
 fi
@@ -47,7 +47,13 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 # the reference's shipped tuning step (TRAIN.MODEL = DenseCLIP): captions as images, global + local head, three prompt sets, EMA loss
 DENSE="python3 $R/bench.py --mode tune --tune-model DenseCLIP --dtype fp16 --steps 4 --warmup 2"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tune_dense -- $DENSE > $OUT/tune_dense.log 2>&1 || exit 1
+# round 5: counter passes of the tuning step (HBM bytes per GEMM launch for its roofline block) and the multi-crop inference path (N2)
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_tune -- $TUNE > $OUT/pmc_fetch_tune.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write_tune -- $TUNE > $OUT/pmc_write_tune.log 2>&1 || exit 1
+MC="python3 $R/bench.py --mode multicrop --steps 5 --warmup 2"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/multicrop -- $MC > $OUT/multicrop.log 2>&1 || exit 1
 cd $R
+timeout -k 10 300 python3 bench.py --mode multicrop > $OUT/multicrop_bench.json 2> $OUT/multicrop_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --mode tune --tune-model DenseCLIP --dtype fp16 --steps 10 --warmup 3 > $OUT/tune_dense_bench.json 2> $OUT/tune_dense_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --arch ViT-L/14@336px --batch 128 --steps 10 --warmup 3 --no-cpu-baseline --no-second-dtype > $OUT/vitl_bench.json 2> $OUT/vitl_bench.err || exit 1
 timeout -k 10 300 python3 bench.py --mode tune --dtype bf16 --steps 10 --warmup 3 > $OUT/tune_bench.json 2> $OUT/tune_bench.err || exit 1

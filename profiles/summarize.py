@@ -7,7 +7,9 @@ TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "gpurun_out", "prof_" + TAG)
 DST = os.path.join(ROOT, "profiles")
-GEMM = "gemm_tn_256x256x64_pp"
+# round 5: the block GEMMs of the large batch run on the 384 x 256 family; the im2col-free patch GEMM stays a 256 x 256 flavour
+GEMM = "gemm_tn_384x256x32_pp" if TAG >= "r05" else "gemm_tn_256x256x64_pp"
+PATCH = "gemm_tn_256x256x64_pp"
 
 
 def newest(pattern):
@@ -70,8 +72,8 @@ for name in ("attn_heads_kernel", "gemm_tn_128x128x64", "image_tail_kernel", "em
     w2, _ = by_kernel(counters("pmc_write"), name)
     out[name] = {"read_bytes_corrected": 2 * f2.get("FETCH_SIZE", 0) * 1024, "write_bytes": w2.get("WRITE_SIZE", 0) * 1024}
 # round 4: the im2col-free patch GEMM (IM2COL flavour <T,0,0,true>) on its own; with embed_ln_pre above it is the whole patch path
-f3, _ = by_kernel(counters("pmc_fetch"), GEMM + "IDF16_Li0ELi0ELb1")
-w3, _ = by_kernel(counters("pmc_write"), GEMM + "IDF16_Li0ELi0ELb1")
+f3, _ = by_kernel(counters("pmc_fetch"), PATCH + "IDF16_Li0ELi0ELb1")
+w3, _ = by_kernel(counters("pmc_write"), PATCH + "IDF16_Li0ELi0ELb1")
 out["patch GEMM (im2col-free)"] = {"read_bytes_corrected": 2 * f3.get("FETCH_SIZE", 0) * 1024, "write_bytes": w3.get("WRITE_SIZE", 0) * 1024}
 pp = out["patch GEMM (im2col-free)"]["read_bytes_corrected"] + out["patch GEMM (im2col-free)"]["write_bytes"] + out["embed_ln_pre"]["read_bytes_corrected"] + out["embed_ln_pre"]["write_bytes"]
 out["patch_path_bytes"] = {"measured": pp, "algorithmic_fp16_image": 256 * 3 * 224 * 224 * 2 + 256 * 197 * 768 * 2 + 768 * 768 * 2,
@@ -124,7 +126,7 @@ def per_shape(sub, out_name):
     alt = 0
     for r in rows_:
         n = r["Kernel_Name"]
-        if GEMM not in n:
+        if GEMM not in n and PATCH not in n:
             continue
         us = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-3
         if "Li2ELi0E" in n:
@@ -157,6 +159,21 @@ def per_shape(sub, out_name):
 
 
 per_shape("trace", f"{TAG}_gemm_shapes.csv")
+# round 5: counter pass of the tuning step (configs[2]): HBM bytes per GEMM launch over every GEMM family of the step
+if os.path.isdir(os.path.join(SRC, "pmc_fetch_tune")):
+    tf_, ntf = by_kernel(counters("pmc_fetch_tune"), "gemm_tn_")
+    tw_, _ = by_kernel(counters("pmc_write_tune"), "gemm_tn_")
+    trd, twr = 2 * tf_.get("FETCH_SIZE", 0) * 1024, tw_.get("WRITE_SIZE", 0) * 1024
+    json.dump({"command": "rocprofv3 --kernel-trace --pmc ... -- python3 bench.py --mode tune --dtype bf16 --steps 4 --warmup 2",
+               "gemm_dispatches_averaged": ntf, "read_bytes_corrected": trd, "write_bytes": twr, "gemm_hbm_bytes_per_launch": trd + twr,
+               "l2_hit_rate": tw_.get("TCC_HIT_sum", 0) / max(tw_.get("TCC_HIT_sum", 0) + tw_.get("TCC_MISS_sum", 0), 1),
+               "note": "every gemm_tn_* dispatch of the step (text tower forward / backward at M = 6 160 .. 18 480, image tower at M = 100 864); FETCH_SIZE x 2 per MI355X_MICROARCH.md"},
+              open(os.path.join(DST, f"{TAG}_tune_pmc_summary.json"), "w"), indent=1)
+if os.path.isdir(os.path.join(SRC, "multicrop")):
+    stats("multicrop", f"{TAG}_multicrop_kernel_stats.csv")
+for src, dst in (("multicrop_bench.json", f"{TAG}_bench_multicrop.json"),):
+    if os.path.exists(os.path.join(SRC, src)):
+        shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
 json.dump(out, open(os.path.join(DST, f"{TAG}_pmc_summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:1200])
 for r in rows[:12]:
