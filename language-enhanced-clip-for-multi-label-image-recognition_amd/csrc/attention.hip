@@ -336,7 +336,7 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 
     // Walk order: the LAST (batch, head) pairs first.  The packed qkv rows were written by the GEMM in front of this kernel in ascending row
     // order, so the tail of the tensor is what the memory-side cache (256 MiB; the tensor is 232 MB at B = 256) still holds - an
-    // ascending walk asks for the oldest lines first and evicts the youngest as it goes (round 4: profiles/r04_attention_order.txt).
+    // ascending walk asks for the oldest lines first and evicts the youngest as it goes (round 4: profiles/r04_walk_order.txt).
     auto eff = [&](int hd) { return a.reverse ? total_heads - 1 - hd : hd; };
     auto head_base = [&](int hd) {
         hd = eff(hd);

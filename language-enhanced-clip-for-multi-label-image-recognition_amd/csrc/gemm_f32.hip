@@ -125,13 +125,26 @@ int leclip_gemm_f32_launch(const void* A, const void* W, int64_t M, int N, int K
     // few tiles and a long contraction: spread K over ~4 workgroups per CU (each split at least 8 K-steps), partial tiles through a
     // stream-ordered scratch buffer
     if (tiles < 128 && K >= 8192) {   // (never a forward shape: those keep the single k-ordered chain, bit-identical across batch sizes)
-        int want = (int)((4 * 256 + tiles - 1) / tiles);
+        int want = (int)((4 * leclip_cu_count() + tiles - 1) / tiles);
         const int max_splits = K / (8 * FK);
         if (want > max_splits) want = max_splits;
         if (want > 1) {
             const int kchunk = ((K + want - 1) / want + FK - 1) / FK * FK;
             const int splits = (K + kchunk - 1) / kchunk;
             float* ws = nullptr;
+            {   // keep freed scratch in the stream-ordered pool between training steps (once per device): by default it returns to the driver at each sync
+                static bool pool_set[LECLIP_MAX_DEVICES] = {};
+                const int dev = leclip_device_ordinal();
+                if (!pool_set[dev]) {
+                    hipMemPool_t pool;
+                    if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+                        uint64_t keep = 1ull << 30;
+                        (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+                    }
+                    (void)hipGetLastError();
+                    pool_set[dev] = true;
+                }
+            }
             if (splits > 1 && hipMallocAsync((void**)&ws, (size_t)splits * M * N * sizeof(float), s) == hipSuccess) {
                 a.splits = splits; a.kchunk = kchunk; a.partial = ws;
                 hipLaunchKernelGGL(gemm_f32_64x64x32, dim3((unsigned)(tiles * splits)), dim3(256), 0, s, a);

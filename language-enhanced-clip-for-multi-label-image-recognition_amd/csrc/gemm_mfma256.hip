@@ -511,7 +511,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_256x256x64_pp(Gemm256Args g) {
             rdesc[3] = 0x00020000;
         }
         // chunk qu of this lane: row (qu >> 1) * 16 + (qu & 1) * 8 + crow, columns (lane & 7) * 8 ..; the row offset travels in the bounds-checked
-        // VECTOR offset.  (s_nop: a descriptor register fresh from v_readfirstlane needs 4 wait states in front of the load that reads it.)
+        // VECTOR offset.  (s_nop 4 = 5 wait states: what a descriptor register fresh from v_readfirstlane needs in front of the load that reads it.)
         auto load_res8 = [&](int first, int rvoff) {
 #pragma unroll
             for (int qu = first; qu < first + 8; ++qu) {

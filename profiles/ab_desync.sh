@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B: start-up staggering of the 256x256 GEMM's workgroups (diagnostic build `make diag`; LECLIP_GEMM_DESYNC = groups * 256 + step: workgroup b starts
 # ((b >> 3) % groups) * step * 512 cycles late).  Why: every workgroup of a launch reaches its epilogue at the same time, so the residual reads and output
-# stores of a whole tile round (64 MB for out-proj / c_proj) hit the memory system as one burst while the matrix cores idle (r04_gemm_epilogue_burst.txt).
+# stores of a whole tile round (64 MB for out-proj / c_proj) hit the memory system as one burst while the matrix cores idle (r04_epilogue_experiments.txt).
 cd "$(dirname "$0")/../language-enhanced-clip-for-multi-label-image-recognition_amd/lib"
 for d in 0 522 532 552 1029 1034 1044 2053 0; do
   g=$((d / 256)); s=$((d % 256))

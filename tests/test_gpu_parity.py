@@ -657,7 +657,7 @@ def test_cfg4_logits_against_the_reference_at_size(ops, golden_dir, dt):
     with torch.no_grad():
         cc.prompt_learner.ctx.copy_(torch.from_numpy(synth.make_ctx(16, 512, seed=0)))
     cc.to(DEV).eval()
-    n = 2048 if dt != torch.float32 else 512            # (the exact-fp32 validation path is 20 x slower: a quarter of the set)
+    n = 2048                                            # every dtype on the whole set (VERDICT r4 weak a: the fp32 leg ran a quarter of it; it costs seconds)
     hip = []
     with torch.no_grad():
         for r in range(n // 256):
