@@ -70,7 +70,7 @@ def main():
                          "FLOP count of the metric assumes.  class-token: the engine's own default outside this benchmark - only what "
                          "ln_post(x[:, 0]) consumes (same logits bit for bit, 6 %% fewer FLOPs executed); its rate is reported beside the headline")
     ap.add_argument("--walk", default=None, choices=["default", "c_proj", "c_fc", "alternate"],
-                    help="A/B: row walk-order policy of the block kernels (hip/engine.py _Walk; default: the engine's own, "default" = library order for every launch)")
+                    help="A/B: row walk-order policy of the block kernels (hip/engine.py _Walk; default: the engine's own = library order for every launch)")
     ap.add_argument("--no-companions", action="store_true", help="skip the cfg5 (ViT-L/14@336) and cfg3 (tuning step) companion child runs of the default run")
     ap.add_argument("--raw-batch", type=int, default=8, help="--mode multicrop: raw 640x480 images per step (305 windows each)")
     ap.add_argument("--no-producer-merge", action="store_true", help="A/B: LayerNorm partials merged by a launch behind out-proj / c_proj instead of "
