@@ -457,7 +457,7 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 }
                 __builtin_amdgcn_s_barrier();
-                if (*(volatile unsigned*)flag) {
+                if (*(volatile __attribute__((address_space(3))) unsigned*)LDS_PTR(flag)) {   // (an LDS read, not a flat one)
                     // 384 rows, 48 per wave, one per lane: the row's pairs slot by slot (consecutive lanes read consecutive pairs of a slot)
                     int lm = lane_e;
                     asm volatile("" : "+v"(lm));
