@@ -56,6 +56,9 @@ struct Gemm384Args {
     EpiParams epi;
     int tiles_n, tiles_total;
     int reverse;   // walk the tiles from the last to the first (leclip_set_walk_order)
+#ifdef LECLIP_DIAG
+    WgLog wglog;   // diagnostic library only: per-workgroup begin / end log (profiles/two_part_timeline.py)
+#endif
 };
 
 __device__ __forceinline__ int xcd_remap384(int bid, int nwg) {
@@ -162,6 +165,10 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
     const EpiParams& e = g.epi;
     const int ns = g.K / KS;   // >= 3 (host)
 
+#ifdef LECLIP_DIAG
+    unsigned long long wl_t0 = 0, wl_c0 = 0;
+    if (g.wglog.buf && tid == 0) { wl_t0 = __builtin_amdgcn_s_memrealtime(); wl_c0 = __builtin_amdgcn_s_memtime(); }
+#endif
     KL<T> p;
     p.smem = smem;
     p.wave1k = wave * 1024;
@@ -491,6 +498,9 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
         n0 = n0n;
         first = false;
     }
+#ifdef LECLIP_DIAG
+    if (g.wglog.buf && tid == 0) wglog_end(g.wglog, 0x300u + (unsigned)(PF * 16 + (CFG & 15)), wl_t0, wl_c0);
+#endif
 }
 
 template <typename T, int PF, int CFG>
@@ -551,5 +561,8 @@ int leclip_gemm384_launch(const void* A, const void* W, int64_t M, int N, int K,
     if (tiles_m * a.tiles_n > 0x7fffffff) { leclip_set_error("gemm: too many tiles"); return LECLIP_E_UNSUPPORTED; }
     a.tiles_total = (int)(tiles_m * a.tiles_n);
     a.reverse = leclip_walk_order() == 1;
+#ifdef LECLIP_DIAG
+    a.wglog = WgLog{g_leclip_wglog, g_leclip_wglog_cap, g_leclip_wglog ? ++g_leclip_wglog_seq : 0u};
+#endif
     return ab_dtype == LECLIP_BF16 ? launch384<bf16_t>(a, s) : launch384<f16_t>(a, s);
 }

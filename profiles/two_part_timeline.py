@@ -88,7 +88,8 @@ def run(streams, steps=3):
     kinds = {}
     for k in np.unique(tag):
         m = tag == k
-        name = NAMES.get(int(k), f"gemm256 PF={(int(k) - 0x100) // 16} CFG={(int(k) - 0x100) % 16}")
+        name = NAMES.get(int(k), (f"gemm384 PF={(int(k) - 0x300) // 16} CFG={(int(k) - 0x300) % 16}" if int(k) >= 0x300 else
+                                  f"gemm256 PF={(int(k) - 0x100) // 16} CFG={(int(k) - 0x100) % 16}"))
         kinds[name] = (len(np.unique(seq[m])), float((t1[m] - t0[m]).sum()) / 100.0 / N_CU, float(np.median(clk[m])), float(np.percentile(clk[m], 10)),
                        float(np.percentile(clk[m], 90)))
     for name, (nl, cu_t, c50, c10, c90) in sorted(kinds.items()):
