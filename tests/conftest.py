@@ -22,3 +22,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _gemm_family_override():
+    """LECLIP_TEST_GEMM_FAMILY=128 | 256 | 384: run the whole GPU suite with that GEMM kernel family forced for every call it can take
+    (leclip_set_gemm_family; the families are bit-identical, so every parity / golden test must pass unchanged) - how a new family is
+    exercised on all the shapes the models produce, not only on its own unit tests.  Tests that assert the DEFAULT dispatch are skipped by
+    their own check of this variable.  Unset: the library's rate heuristic (the product)."""
+    fam = os.environ.get("LECLIP_TEST_GEMM_FAMILY")
+    if fam:
+        from leclip_amd.hip import ops
+        ops.set_gemm_family(int(fam))
+    yield

@@ -81,6 +81,8 @@ def test_gemm_kernel_families(ops):
     """The dispatcher: the 384x256 ping-pong kernel (round 5) from 160 of its tiles up, the 256x256 one from 96 of its tiles, 128x128 otherwise;
     against fp64."""
     from leclip_amd.hip import _capi
+    if os.environ.get("LECLIP_TEST_GEMM_FAMILY"):
+        pytest.skip("the default dispatch is not in effect under LECLIP_TEST_GEMM_FAMILY")
     lib = _capi.load()
     assert lib.leclip_gemm_kernel_name(50432, 768, 768, _capi.BF16) == b"gemm_tn_384x256x32_pp"
     assert lib.leclip_gemm_kernel_name(12608, 768, 768, _capi.BF16) == b"gemm_tn_256x256x64_pp"      # 99 tiles of 384x256, 150 of 256x256
@@ -250,6 +252,8 @@ def test_gemm_families_are_bit_identical(ops, dt):
     the logits.  Every epilogue flavour: plain, +bias+QuickGELU, +residual (+LayerNorm partial sums), fused LayerNorm
     (+QuickGELU), 16-bit and fp32 output."""
     lib = ops._capi.load()
+    if os.environ.get("LECLIP_TEST_GEMM_FAMILY"):
+        pytest.skip("compares the families under its own overrides")
     g = torch.Generator(device="cpu").manual_seed(11)
     for (M, N, K) in ((50432, 768, 768), (30000, 2304, 768), (20000, 768, 3072)):
         ms = 197 * 3 + 5
