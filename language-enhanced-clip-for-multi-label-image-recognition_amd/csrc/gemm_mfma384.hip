@@ -23,12 +23,16 @@
 // LDS-DMA through buffer descriptors rebuilt per tile on the scalar unit (base = the tile's first row, size = its valid rows: rows past M read as
 // zero), one 32-bit per-lane offset per piece, the K offset in the scalar offset.  Same 64-byte-row XOR swizzle as the 256 x 256 kernel.
 //
-// Epilogues: the 256 x 256 kernel's "T16" code re-cut for 16 x 128 strips (6 per wave) - MFMA operands swapped so that a lane holds 4 consecutive
-// columns; bias / fused LayerNorm / QuickGELU in the accumulator layout; the branch value rounded to T and parked through ONE wave-private LDS
-// strip (a wave's LDS operations execute in order: write -> read-back -> next write need no waits); read back 16 lanes per row, 16 bytes per
-// lane; 16-bit residual added after the read-back (the reference's two roundings, clip/model.py:225-228), LayerNorm partials from the stored
-// values with the 256 x 256 kernel's additions in its order.  Column constants and the tile's (mean, rstd) rows travel by LDS-DMA into a constants
-// region ahead of the last two steps.  Flavours: residual (+ partials) [out-proj, c_proj], fused LayerNorm (+ QuickGELU) [qkv, c_fc], plain bias.
+// Epilogues: the 256 x 256 kernel's "T16" arithmetic re-cut for 16 x 128 strips (6 per wave), in TWO passes - MFMA operands swapped so that a lane
+// holds 4 consecutive columns; pass 1, column block by column block: bias / fused LayerNorm / QuickGELU in the accumulator layout with the block's
+// constants read from LDS once per tile, the branch value rounded to T in place (4 registers become 2) and the freed registers taking the first
+// residual chunks; pass 2, strip by strip: parked through ONE wave-private LDS strip (a wave's LDS operations execute in order: write ->
+// read-back -> next write need no waits), read back 16 lanes per row, 16 bytes per lane; 16-bit residual added after the read-back (the
+// reference's two roundings, clip/model.py:225-228), LayerNorm partials from the stored values with the 256 x 256 kernel's additions in its
+// order.  Column constants and the tile's (mean, rstd) rows travel by LDS-DMA into a constants region ahead of the last two steps.
+// Flavours: residual (+ partials) [out-proj, c_proj: clip/model.py:226-227], fused LayerNorm (+ QuickGELU) [qkv, c_fc: :212-218, :221-223], plain bias.
+// With EpiParams::stats_merged (leclip_gemm_res_stats_fwd) the LAST of a 384-row block's N / 256 workgroups to finish merges the block's partials
+// into (mean, rstd) inside the launch - what the next LayerNorm's statistics pass (clip/model.py:193-199) would compute.
 #include "leclip_common.h"
 #include <stdlib.h>
 
