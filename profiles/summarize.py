@@ -49,7 +49,8 @@ stats("vitl", f"{TAG}_vitl_kernel_stats.csv")
 stats("tune", f"{TAG}_tune_kernel_stats.csv")
 if os.path.isdir(os.path.join(SRC, "tune_dense")):
     stats("tune_dense", f"{TAG}_tune_dense_kernel_stats.csv")
-for src, dst in (("bench.json", f"{TAG}_bench.json"), ("vitl_bench.json", f"{TAG}_vitl_bench.json"), ("tune_bench.json", f"{TAG}_bench_tune.json"),
+# (bench.json of the collection run is copied only when no newer line has been committed by hand: the round's final line is taken after the last code change)
+for src, dst in ((("bench.json", f"{TAG}_bench.json"),) if not os.path.exists(os.path.join(DST, f"{TAG}_bench.json")) else ()) + (("vitl_bench.json", f"{TAG}_vitl_bench.json"), ("tune_bench.json", f"{TAG}_bench_tune.json"),
                  ("tune_dense_bench.json", f"{TAG}_bench_tune_dense.json")):
     if os.path.exists(os.path.join(SRC, src)):
         shutil.copy(os.path.join(SRC, src), os.path.join(DST, dst))
@@ -67,6 +68,23 @@ out[GEMM] = {"dispatches_averaged": nf, "FETCH_SIZE_KB": fetch.get("FETCH_SIZE")
              "SQ": sq, "GRBM_GUI_ACTIVE": grbm.get("GRBM_GUI_ACTIVE"),
              "mfma_busy_frac_of_simd_cycles": sq.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(grbm.get("GRBM_GUI_ACTIVE", 0) / 8 * 1024, 1)}
 out["gemm_hbm_bytes_per_launch"] = rd + wr
+if TAG >= "r05":
+    # per flavour (the residual flavour serves out-proj and c_proj alternately: split at the median of its read bytes); algorithmic = A + W (+ residual) read
+    pf_, pw_ = counters("pmc_fetch"), counters("pmc_write")
+    flav = {}
+    for tag_, name_, alg in (("Li2ELi0E", "qkv (LN fused)", 50432 * 768 * 2 + 2304 * 768 * 2), ("Li2ELi1E", "c_fc (LN + QuickGELU fused)", 50432 * 768 * 2 + 3072 * 768 * 2)):
+        r_ = [2 * v["FETCH_SIZE"] * 1024 for (k, _), v in pf_.items() if GEMM in k and tag_ in k and v["FETCH_SIZE"] * 2048 > 1.5e8]
+        w_ = [v["WRITE_SIZE"] * 1024 for (k, _), v in pw_.items() if GEMM in k and tag_ in k and v["WRITE_SIZE"] * 1024 > 1e8]
+        if r_ and w_:
+            flav[name_] = {"dispatches": len(r_), "read_bytes_corrected": sum(r_) / len(r_), "write_bytes": sum(w_) / len(w_), "algorithmic_read_bytes": alg,
+                           "read_over_algorithmic": sum(r_) / len(r_) / alg}
+    r_ = sorted(2 * v["FETCH_SIZE"] * 1024 for (k, _), v in pf_.items() if GEMM in k and "Li1ELi2E" in k)
+    if r_:
+        h = len(r_) // 2
+        for name_, part, alg in (("out_proj (+residual, +partials, in-producer merge)", r_[:h], 2 * 50432 * 768 * 2 + 768 * 768 * 2),
+                                 ("c_proj (+residual, +partials, in-producer merge)", r_[h:], 50432 * 3072 * 2 + 50432 * 768 * 2 + 768 * 3072 * 2)):
+            flav[name_] = {"dispatches": len(part), "read_bytes_corrected": sum(part) / len(part), "algorithmic_read_bytes": alg, "read_over_algorithmic": sum(part) / len(part) / alg}
+    out["gemm_read_traffic_per_shape"] = flav
 for name in ("attn_heads_kernel", "gemm_tn_128x128x64", "image_tail_kernel", "embed_ln_pre"):
     f2, _ = by_kernel(counters("pmc_fetch"), name)
     w2, _ = by_kernel(counters("pmc_write"), name)
