@@ -200,7 +200,15 @@ __global__ __launch_bounds__(512, 2) void gemm_tn_384x256x32_pp(Gemm384Args g) {
     auto tile_origin = [&](int v, int64_t& m0, int& n0) {
         if (g.reverse) v = g.tiles_total - 1 - v;
         const int tile = xcd_remap384(v, g.tiles_total);
-        const int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+        int tm = tile / g.tiles_n, tn = tile - tm * g.tiles_n;
+#ifdef LECLIP_G384_NGROUP   // A/B builds: N-tiles in groups of NGROUP, (group, row block, tile in group) order: an XCD's chunk stays on one group's W panel
+        if (g.tiles_n > LECLIP_G384_NGROUP && g.tiles_n % LECLIP_G384_NGROUP == 0) {
+            const int per_group = (g.tiles_total / g.tiles_n) * LECLIP_G384_NGROUP;
+            const int grp_ = tile / per_group, rem = tile - grp_ * per_group;
+            tm = rem / LECLIP_G384_NGROUP;
+            tn = grp_ * LECLIP_G384_NGROUP + (rem - tm * LECLIP_G384_NGROUP);
+        }
+#endif
         m0 = (int64_t)tm * TM;
         n0 = tn * TN;
     };
