@@ -36,6 +36,25 @@ def test_library_exports_every_declared_symbol():
     assert _capi.load().leclip_set_gemm_family(-1) == 384
 
 
+def test_entry_points_refuse_bad_arguments_before_any_launch():
+    """Error behaviour of the C ABI (return codes, never exceptions or aborts; the message through leclip_last_error): null
+    pointers / inconsistent sizes / misaligned scratch are refused by the host-side checks - no device needed to see that."""
+    from leclip_amd.hip import _capi
+    lib = _capi.load()
+    F16 = _capi.F16
+    rc = lib.leclip_gemm_res_stats_fwd(None, None, None, None, None, None, None, None, 1e-5, 50432, 768, 768, 768, 768, 768, 768, F16, F16, F16, None)
+    assert rc == -1 and b"gemm_res_stats" in lib.leclip_last_error()
+    rc = lib.leclip_gemm_res_stats_fwd(16, 16, None, 16, 16, 16, 16, None, 1e-5, 100, 768, 768, 700, 768, 768, 768, F16, F16, F16, None)     # lda < K
+    assert rc == -1
+    rc = lib.leclip_gemm_res_stats_fwd(16, 16, None, 16, 16, 16, 16, None, 1e-5, 100, 768, 768, 768, 768, 768, 768, _capi.F32, F16, F16, None)  # fp32 operands
+    assert rc == -2 and lib.leclip_strerror(rc) == b"unsupported shape or dtype"
+    rc = lib.leclip_gemm_res_stats_fwd(16, 16, None, 16, 16, 20, 16, None, 1e-5, 100, 768, 768, 768, 768, 768, 768, F16, F16, F16, None)      # partials_ws not 16-byte aligned
+    assert rc == -1 and b"aligned" in lib.leclip_last_error()
+    rc = lib.leclip_gemm_bias_act_res_fwd(None, None, None, None, None, 10, 128, 64, 64, 64, 128, 128, 0, F16, F16, F16, None)
+    assert rc == -1
+    assert lib.leclip_ln_stats_finalize_fwd(None, None, 0, 0, 0, 1e-5, None) == -1
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from leclip_amd.hip import _capi
     monkeypatch.setattr(_capi, "_lib", None)
