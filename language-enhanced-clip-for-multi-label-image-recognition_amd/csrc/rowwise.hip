@@ -569,6 +569,54 @@ void im2col8_out(const void* image, void* patches, int64_t n_rows, int R, int P,
     else hipLaunchKernelGGL((im2col8_kernel<TI, bf16_t>), grid, block, 0, s, (const TI*)image, (bf16_t*)patches, n_rows, R, P, Kp);
 }
 
+// P even but not a multiple of 8 (ViT-L/14: 14-pixel patch rows, 28 bytes in 16 bits - round 5): one thread per 8 consecutive k of a patch row, its
+// four pixel PAIRS decoded one by one (a pair never straddles a patch row: P and k are even), one 16-byte store; consecutive threads write consecutive
+// chunks.  The one-thread-per-pixel-run kernel above moved ViT-L/14@336's 181 MB with 2-byte accesses in 236 us.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void im2col2_kernel(const TI* __restrict__ image, TO* __restrict__ patches, int64_t n_rows, int R, int P, int Kp) {
+    const int chunks = Kp >> 3;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_rows * chunks) return;
+    const int64_t r = i / chunks;
+    const int k0 = (int)(i - r * chunks) * 8;
+    const int G = R / P, PP = P * P;
+    const int gx = (int)(r % G), gy = (int)((r / G) % G);
+    const int64_t b = r / ((int64_t)G * G);
+    const TI* img = image + ((b * 3) * R + gy * P) * (int64_t)R + gx * P;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 2 * u;
+        v[2 * u] = 0.f; v[2 * u + 1] = 0.f;
+        if (k < 3 * PP) {
+            const int c = k / PP, rem = k - c * PP, py = rem / P, px = rem - py * P;
+            const TI* src = img + ((int64_t)c * R + py) * R + px;
+            if constexpr (sizeof(TI) == 4) { const f32x2 t = *(const f32x2*)src; v[2 * u] = t[0]; v[2 * u + 1] = t[1]; }
+            else {
+                typedef TI t2 __attribute__((ext_vector_type(2)));
+                const t2 t = *(const t2*)src;
+                v[2 * u] = (float)t[0]; v[2 * u + 1] = (float)t[1];
+            }
+        }
+    }
+    TO* dst = patches + r * Kp + k0;
+#pragma unroll
+    for (int e = 0; e < 8; e += 4) {
+        f32x4 t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) t[u] = v[e + u];
+        store4<TO>(dst + e, t);
+    }
+}
+
+template <typename TI>
+void im2col2_out(const void* image, void* patches, int64_t n_rows, int R, int P, int Kp, int odt, hipStream_t s) {
+    const dim3 grid((unsigned)((n_rows * (Kp / 8) + 255) / 256)), block(256);
+    if (odt == LECLIP_F32) hipLaunchKernelGGL((im2col2_kernel<TI, float>), grid, block, 0, s, (const TI*)image, (float*)patches, n_rows, R, P, Kp);
+    else if (odt == LECLIP_F16) hipLaunchKernelGGL((im2col2_kernel<TI, f16_t>), grid, block, 0, s, (const TI*)image, (f16_t*)patches, n_rows, R, P, Kp);
+    else hipLaunchKernelGGL((im2col2_kernel<TI, bf16_t>), grid, block, 0, s, (const TI*)image, (bf16_t*)patches, n_rows, R, P, Kp);
+}
+
 __global__ void class_rows_kernel(const float* __restrict__ cls, const float* __restrict__ pos, void* __restrict__ X,
                                   int T, int width, int xdt) {
     const int64_t b = blockIdx.x;
@@ -688,6 +736,11 @@ extern "C" int leclip_patch_embed_fwd(const void* image, const void* Wp, const f
         if (img_dtype == LECLIP_F32) im2col8_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
         else if (img_dtype == LECLIP_F16) im2col8_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
         else im2col8_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+    } else if (P % 2 == 0 && R % 2 == 0 && ((uintptr_t)image & 7) == 0) {
+        const int64_t n_rows = B * G * G;
+        if (img_dtype == LECLIP_F32) im2col2_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else if (img_dtype == LECLIP_F16) im2col2_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else im2col2_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
     } else {
         hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp,
                            (int)img_dtype, (int)w_dtype);
@@ -732,6 +785,10 @@ extern "C" int leclip_patch_embed_ln_fwd(const void* image, const void* Wp, cons
         if (img_dtype == LECLIP_F32) im2col8_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
         else if (img_dtype == LECLIP_F16) im2col8_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
         else im2col8_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+    } else if (P % 2 == 0 && R % 2 == 0 && ((uintptr_t)image & 7) == 0) {     // ViT-L/14: pixel pairs, 16-byte stores (round 5)
+        if (img_dtype == LECLIP_F32) im2col2_out<float>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else if (img_dtype == LECLIP_F16) im2col2_out<f16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
+        else im2col2_out<bf16_t>(image, workspace, n_rows, R, P, Kp, (int)w_dtype, s);
     } else {
         const int64_t total = n_rows * 3 * P;
         hipLaunchKernelGGL(im2col_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, image, workspace, B, R, P, Kp, (int)img_dtype, (int)w_dtype);

@@ -497,6 +497,10 @@ def test_patch_embed(ops, dt, geom):
     wp[:, :k] = w.reshape(width, k)
     x = ops.patch_embed(img.to(DEV), wp.to(DEV), cls.to(DEV), pos.to(DEV), p, dt)
     np.testing.assert_allclose(x.float().cpu().numpy(), ref.numpy(), atol=_tol(dt, 1e-5, 6e-3, 5e-2), rtol=0)
+    # the same pixel values handed over in the compute dtype (what bench.py does): the extraction kernels' 16-bit-input forms - 8-pixel chunks
+    # for 8 | P, pixel pairs for patch 14 (round 5) - must give the same bits as their fp32-input forms
+    x16 = ops.patch_embed(img.to(dt).to(DEV), wp.to(DEV), cls.to(DEV), pos.to(DEV), p, dt)
+    assert torch.equal(x16, x)
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
