@@ -382,6 +382,9 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 #endif
     int hd = blockIdx.x;
     const bool active = wave * 32 < a.T;   // wave-uniform
+#ifdef LECLIP_ATTN_YOUNG_PRIO   // A/B builds: static priority for the second-dispatched half (MI355X_MICROARCH.md, two waves per SIMD, item 4)
+    if (wave >= 4) __builtin_amdgcn_s_setprio(LECLIP_ATTN_YOUNG_PRIO);
+#endif
     {
         const T* base = head_base(hd);
         issue(base, 0);
