@@ -398,6 +398,9 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
         // One barrier per head: every wave has (a) finished head it-1, so buffer cur^1 may be overwritten, and
         // (b) passed the counted wait at the end of its previous iteration, so every share of head `hd` is in buffer cur.
         __builtin_amdgcn_s_barrier();
+#ifdef LECLIP_ATTN_SKEW   // A/B builds: waves 4..7 start each head LECLIP_ATTN_SKEW x 64 cycles late, so that a SIMD's two waves are a phase apart
+        if (wave >= 4) __builtin_amdgcn_s_sleep(LECLIP_ATTN_SKEW);
+#endif
         const T* nb = head_base(nxt_c);
         if (active) {
             v8 q[4];

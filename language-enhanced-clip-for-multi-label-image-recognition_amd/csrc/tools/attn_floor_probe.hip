@@ -18,7 +18,7 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 constexpr int T = 197, HEADS = 12, D = 768, ROW = 3 * D * 2, OROW = D * 2;   // bytes
 constexpr int PIECES = 75;   // 25 pieces of 8 rows for each of q, k, v (the last piece of each repeats row 196)
 
-template <bool STORE, bool LOAD>
+template <bool STORE, bool LOAD, int LOOK = 1>
 __global__ __launch_bounds__(512) void stream_heads(const char* qkv, char* out, int pairs, int reverse, int* sink) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // two heads x 75 KiB
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -34,7 +34,8 @@ __global__ __launch_bounds__(512) void stream_heads(const char* qkv, char* out, 
                 const char* p = qkv + ((int64_t)b * T + row) * ROW + (pc / 25) * (D * 2) + h * 128 + (lane & 7) * 16;
                 __builtin_amdgcn_global_load_lds((const void*)p, LDS_PTR(smem + ((it & 1) * PIECES + pc) * 1024), 16, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + (STORE ? 4 : 0)) : "memory");   // the previous head's pieces have landed, this head's (and the last stores) stay in flight
+            if (LOOK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 + (STORE ? 4 : 0)) : "memory");   // the previous head's pieces have landed, this head's (and the last stores) stay in flight
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                     // LOOK = 0: no head in flight across the barrier
         }
         __builtin_amdgcn_s_barrier();
         if (STORE) {
@@ -85,6 +86,7 @@ int main() {
         run("loads + stores (the kernel's traffic)", stream_heads<true, true>, qkv, out, B, sink, rd + wr);
         run("loads only", stream_heads<false, true>, qkv, out, B, sink, rd);
         run("stores only", stream_heads<true, false>, qkv, out, B, sink, wr);
+        run("loads + stores, NO head of lookahead", stream_heads<true, true, 0>, qkv, out, B, sink, rd + wr);
     }
     return 0;
 }
