@@ -86,7 +86,11 @@ __device__ __forceinline__ void attn_load_q(const AttnArgs& a, const T* base, in
 
 // STORE_ALL: lanes whose query index is past T store the (identical) result of the clamped row T-1 instead of being
 // masked off, so every wave issues the same number of store instructions (counted vmcnt waits in the pipelined kernel).
-template <typename T, int NKT, bool STORE_ALL>
+// LIVE: how many of the LAST key tile's four 8-key groups can hold a valid key (T - 32 (NKT - 1) <= 8 LIVE; 4 = no assumption).  A lane's registers
+// 4 g .. 4 g + 3 of a score tile are the keys of group g, so a dead group's mask, maximum, exponentials and conversions are not issued at all
+// and - LIVE <= 2 - neither is the tile's second P.V step (its probabilities are exact zeros: the result is the same bits).  ViT-B/16: T = 197,
+// five keys in the seventh tile, LIVE = 1: 12 of a lane's 112 exponentials and 2 of 28 P.V MFMAs per query block.
+template <typename T, int NKT, bool STORE_ALL, int LIVE = 4>
 __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, const char* sV,
                                             const typename VecOf<T>::v8 (&qf)[4], T* obase, int qb, int lane) {
     typedef typename VecOf<T>::v8 v8;
@@ -160,15 +164,16 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
             // a key tile needs masking only if it reaches past the last valid key (wave-uniform test): for the
             // unmasked image tower that is the final tile alone
             const bool partial = a.causal || (kt * 32 + 31 > a.T - 1);
+            const int nr = kt == NKT - 1 ? 4 * LIVE : 16;   // registers of this tile that can hold a valid key
             if (partial) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < nr; ++r) {
                     const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                     sc[kt][r] = key <= klimit ? sc[kt][r] : -3.0e38f;
                 }
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+            for (int r = 0; r < nr; ++r) mx = fmaxf(mx, sc[kt][r]);
         }
         mx = lane32_max(mx);   // the query's other lane (v_permlane32_swap: no LDS round trip)
         const float mb = mx * a.scale_log2e;
@@ -181,6 +186,11 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
+                if (kt == NKT - 1 && r >= 4 * LIVE) {   // a dead group: what the masked path computes for it, without computing it
+                    sc[kt][r] = 0.f;
+                    sc[kt][r + 1] = 0.f;
+                    continue;
+                }
                 // v_exp_f32 directly: arguments are <= 0, results below 2^-126 flush to 0 (masked keys: exactly 0)
                 f2 x = {sc[kt][r], sc[kt][r + 1]};
                 x = __builtin_elementwise_fma(x, scl2, nmb2);
@@ -235,20 +245,22 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                 asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2"                                                    \
                              : "=v"(vr[slot][i * 2 + u])                                                              \
                              : "v"(i ? va1 : va0), "n"((((step) >> 1) * 32 + 16 * ((step) & 1) + 8 * u) * 128));
+            constexpr int NPV = 2 * NKT - (LIVE <= 2 ? 1 : 0);   // 16-key P.V steps: the last tile's second step is all zeros when its groups 2, 3 are dead
+            static_assert(NPV >= 2, "ring primes two steps");
             TR_ISSUE(0, 0)
             TR_ISSUE(1, 1)
 #pragma unroll
-            for (int st = 0; st < 2 * NKT; ++st) {
+            for (int st = 0; st < NPV; ++st) {
                 const int kt = st >> 1, s2 = st & 1, slot = st % 3;
-                if (st + 2 < 2 * NKT) {
+                if (st + 2 < NPV) {
                     if (slot == 0) { TR_ISSUE(2, st + 2) } else if (slot == 1) { TR_ISSUE(0, st + 2) } else { TR_ISSUE(1, st + 2) }
                 }
                 v8 pf;
 #pragma unroll
                 for (int j = 0; j < 8; ++j) pf[j] = (T)sc[kt][8 * s2 + j];
                 // DS operations return in order: everything but the 4 reads of each younger step has arrived
-                if (st + 2 < 2 * NKT) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
-                else if (st + 1 < 2 * NKT) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                if (st + 2 < NPV) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+                else if (st + 1 < NPV) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 v8 vf[2];
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void attn_rows_kernel(AttnArgs a) {
 // is computed; wave w owns query block w.  The wait is counted: every wave ends a head with exactly 4 output stores,
 // so "all but the newest 4" retires its share of the next head's K/V and Q without draining those stores.  One barrier
 // per head.
-template <typename T, int NKT>
+template <typename T, int NKT, int LIVE>
 __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int total_heads) {
     typedef typename VecOf<T>::v8 v8;
     constexpr int TP = NKT * 32, BUF = TP * 128;
@@ -412,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
             const int he = eff(hd);
             const int b = he / a.heads, h = he - b * a.heads;
             T* obase = (T*)a.out + (int64_t)b * a.T * a.ld_out + h * 64;
-            attn_qblock<T, NKT, true>(a, smem + cur * 2 * BUF, smem + cur * 2 * BUF + BUF, q, obase, wave, lane);
+            attn_qblock<T, NKT, true, LIVE>(a, smem + cur * 2 * BUF, smem + cur * 2 * BUF + BUF, q, obase, wave, lane);
             // Everything older than this head's 4 output stores has completed: the next head's K/V share and Q image
             // (issued a whole head ago) are in, without draining the stores just issued.
             asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -851,8 +863,25 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
         const int n_cu = leclip_cu_count();
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
         constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
-        leclip_set_max_lds(attn_heads_kernel<T, 7>, LDSB, attr_set);
-        hipLaunchKernelGGL((attn_heads_kernel<T, 7>), dim3(grid < (unsigned)n_cu ? grid : (unsigned)n_cu), dim3(512), LDSB, s, a, (int)grid);
+        const dim3 g(grid < (unsigned)n_cu ? grid : (unsigned)n_cu);
+        const int live = (a.T - 192 + 7) >> 3;   // 8-key groups of the seventh key tile that hold a valid key (T = 197: one)
+#ifdef LECLIP_ATTN_NO_DEAD_GROUPS   // A/B builds: the round-4 kernel (every group of the last tile computed and masked)
+        const int live_k = 4 + 0 * live;
+#else
+        const int live_k = live <= 1 ? 1 : live <= 2 ? 2 : 4;
+#endif
+        if (live_k == 1) {
+            static bool attr1[LECLIP_MAX_DEVICES] = {};
+            leclip_set_max_lds(attn_heads_kernel<T, 7, 1>, LDSB, attr1);
+            hipLaunchKernelGGL((attn_heads_kernel<T, 7, 1>), g, dim3(512), LDSB, s, a, (int)grid);
+        } else if (live_k == 2) {
+            static bool attr2[LECLIP_MAX_DEVICES] = {};
+            leclip_set_max_lds(attn_heads_kernel<T, 7, 2>, LDSB, attr2);
+            hipLaunchKernelGGL((attn_heads_kernel<T, 7, 2>), g, dim3(512), LDSB, s, a, (int)grid);
+        } else {
+            leclip_set_max_lds(attn_heads_kernel<T, 7, 4>, LDSB, attr_set);
+            hipLaunchKernelGGL((attn_heads_kernel<T, 7, 4>), g, dim3(512), LDSB, s, a, (int)grid);
+        }
         return leclip_check_launch("attn_heads_kernel");
     }
     if (a.T <= 32) hipLaunchKernelGGL((attn_rows_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a);

@@ -429,10 +429,12 @@ def test_attention_long_late_maxima(ops, dt, cfg):
 
 
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
-@pytest.mark.parametrize("cfg", [(86, 197, 12), (43, 224, 24), (22, 193, 48), (300, 197, 12)])
+@pytest.mark.parametrize("cfg", [(86, 197, 12), (43, 224, 24), (22, 193, 48), (300, 197, 12), (86, 200, 12), (86, 201, 12), (86, 208, 12), (86, 209, 12)])
 def test_attention_many_heads(ops, dt, cfg):
     """>= 1024 (batch, head) pairs with 193..224 tokens run the persistent pipelined kernel (attn_heads_kernel): head counts
-    that are not a multiple of the CU count leave workgroups with different numbers of heads."""
+    that are not a multiple of the CU count leave workgroups with different numbers of heads.  T = 193..200 / 201..208 / 209..224 are the kernel's
+    three instances (1 / 2 / all 4 of the last key tile's 8-key groups computed): each boundary is a case, and each must give the bits of the
+    one-workgroup-per-head kernel, which computes and masks every group."""
     b, t, h = cfg
     d = 64 * h
     qkv = _rand((b * t, 3 * d), 31).to(dt)
@@ -442,6 +444,8 @@ def test_attention_many_heads(ops, dt, cfg):
     err = float((y.float() - ref).abs().max())
     assert err <= _tol(dt, 2e-5, 4e-3, 2.5e-2), err
     assert torch.equal(y, ops.attention(qkv.to(DEV), b, t, h, False))     # deterministic
+    nb = max(1, 1023 // h)                                                 # < 1024 pairs: attn_rows_kernel
+    assert nb < b and torch.equal(y[:nb * t], ops.attention(qkv[:nb * t].to(DEV), nb, t, h, False))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
