@@ -12,6 +12,10 @@
 #include "leclip_common.h"
 #include <stdlib.h>
 
+#ifndef LECLIP_ATTN_V2
+#define LECLIP_ATTN_V2 0
+#endif
+
 namespace {
 
 struct AttnArgs {
@@ -130,10 +134,20 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                 const int kt = st >> 2, s = st & 3;
                 if (st + KR - 1 < NST) K_ISSUE(st + KR - 1);
                 // DS operations return in order: all but the reads of the younger steps have arrived
+#if LECLIP_ATTN_V2 & 1
+                // (the wait names no register: as an in/out operand of the wait the fragment looked like a fresh vector result to hipcc, which put an
+                //  s_nop - four cycles of the SIMD's issue - in front of each of the 28 MFMAs; the scheduling fence below keeps the MFMA behind the wait)
+                if (st + KR - 1 < NST) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KR - 1) : "memory");
+                else if (st + 2 < NST) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else if (st + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#else
                 if (st + KR - 1 < NST) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kr[st % KR]) : "n"(KR - 1));
                 else if (st + 2 < NST) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kr[st % KR]));
                 else if (st + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kr[st % KR]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[st % KR]));
+#endif
                 if (s == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
@@ -159,6 +173,9 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
         // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
         const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
         float mx = -3.0e38f;
+#if LECLIP_ATTN_V2 & 4
+        float mx_b = -3.0e38f;
+#endif
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             // a key tile needs masking only if it reaches past the last valid key (wave-uniform test): for the
@@ -172,15 +189,26 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                     sc[kt][r] = key <= klimit ? sc[kt][r] : -3.0e38f;
                 }
             }
+#if LECLIP_ATTN_V2 & 4
+#pragma unroll
+            for (int r = 0; r < nr; r += 2) { mx = fmaxf(mx, sc[kt][r]); mx_b = fmaxf(mx_b, sc[kt][r + 1]); }   // two chains (max is exact: any order gives the same value)
+#else
 #pragma unroll
             for (int r = 0; r < nr; ++r) mx = fmaxf(mx, sc[kt][r]);
+#endif
         }
+#if LECLIP_ATTN_V2 & 4
+        mx = fmaxf(mx, mx_b);
+#endif
         mx = lane32_max(mx);   // the query's other lane (v_permlane32_swap: no LDS round trip)
         const float mb = mx * a.scale_log2e;
         // Two keys at a time as a float pair: the scale-and-shift and the row sum issue as packed fp32 instructions (v_pk_fma_f32 /
         // v_pk_add_f32: half the issue slots of that half of the softmax; the sum runs as an even-key and an odd-key partial).
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 sum2 = {0.f, 0.f};
+#if LECLIP_ATTN_V2 & 2
+        f2 sum2b = {0.f, 0.f};   // second pair of partial sums: four independent chains instead of two
+#endif
         const f2 scl2 = (f2)(a.scale_log2e), nmb2 = (f2)(-mb);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -192,14 +220,27 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                     continue;
                 }
                 // v_exp_f32 directly: arguments are <= 0, results below 2^-126 flush to 0 (masked keys: exactly 0)
+#if LECLIP_ATTN_V2 & 8
+                const float x0 = __builtin_fmaf(sc[kt][r], a.scale_log2e, -mb), x1 = __builtin_fmaf(sc[kt][r + 1], a.scale_log2e, -mb);
+                const f2 p = {__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1)};
+#else
                 f2 x = {sc[kt][r], sc[kt][r + 1]};
                 x = __builtin_elementwise_fma(x, scl2, nmb2);
                 const f2 p = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
+#endif
                 sc[kt][r] = p.x;
                 sc[kt][r + 1] = p.y;
+#if LECLIP_ATTN_V2 & 2
+                if (r & 2) { sum2b.x += p.x; sum2b.y += p.y; } else { sum2.x += p.x; sum2.y += p.y; }
+#else
                 sum2 += p;
+#endif
             }
+#if LECLIP_ATTN_V2 & 2
+        const float sum = lane32_sum((sum2.x + sum2.y) + (sum2b.x + sum2b.y));
+#else
         const float sum = lane32_sum(sum2.x + sum2.y);
+#endif
         const float inv = 1.0f / sum;
 
         // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
@@ -350,40 +391,54 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     // order, so the tail of the tensor is what the memory-side cache (256 MiB; the tensor is 232 MB at B = 256) still holds - an
     // ascending walk asks for the oldest lines first and evicts the youngest as it goes (round 4: profiles/r04_walk_order.txt).
     auto eff = [&](int hd) { return a.reverse ? total_heads - 1 - hd : hd; };
-    auto head_base = [&](int hd) {
+    // A head's source as a buffer descriptor built on the scalar unit (base = q[b, 0, head, 0], size = the rest of the image's rows), so that the
+    // per-lane part of every piece's address is a 32-bit byte offset that does not change from head to head: the loop's LDS-DMA issue costs no
+    // vector address arithmetic (as global_load_lds with 64-bit lane addresses it was 33 vector instructions per head and wave).
+    auto head_rsrc = [&](int hd) {
         hd = eff(hd);
         const int b = hd / a.heads, h = hd - b * a.heads;
-        return (const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64;
+        const char* base = (const char*)((const T*)a.qkv + (int64_t)b * a.T * a.ld_qkv + h * 64);
+        const unsigned long long v = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        const unsigned size = __builtin_amdgcn_readfirstlane((unsigned)((int64_t)a.T * a.ld_qkv * 2 - h * 128));
+        return __builtin_amdgcn_make_buffer_rsrc((char*)(((unsigned long long)hi << 32) | lo), 0, (int)size, 0x00020000);
     };
     // K then V, TP/8 pieces of 8 rows x 128 B each; wave w takes pieces w, w+8, ... (NKT per wave)
-    auto issue = [&](const T* base, int buf) {
+    unsigned kv_off[NKT], q_off[4];
+    int kv_dst[NKT];
 #pragma unroll
-        for (int u = 0; u < NKT; ++u) {
-            const int pc = wave + 8 * u;
-            const int isv = pc >= TP / 8 ? 1 : 0;
-            const int piece = pc - isv * (TP / 8);
-            const int row = piece * 8 + (lane >> 3);
-            const int p = lane & 7;
-            const int c = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
-            const int grow = row < a.T ? row : a.T - 1;
-            const T* src = base + (int64_t)grow * a.ld_qkv + (1 + isv) * d_model + c * 8;
-            __builtin_amdgcn_global_load_lds((const void*)src, LDS_PTR(smem + buf * 2 * BUF + isv * BUF + piece * 1024), 16, 0, 0);
-        }
+    for (int u = 0; u < NKT; ++u) {
+        const int pc = wave + 8 * u;
+        const int isv = pc >= TP / 8 ? 1 : 0;
+        const int piece = pc - isv * (TP / 8);
+        const int row = piece * 8 + (lane >> 3);
+        const int p = lane & 7;
+        const int c = isv ? (p ^ (((row >> 1) & 1) << 2)) : (p ^ ((row >> 1) & 7));
+        const int grow = row < a.T ? row : a.T - 1;
+        kv_off[u] = (unsigned)grow * (unsigned)a.ld_qkv * 2u + (unsigned)((1 + isv) * d_model * 2 + c * 16);
+        kv_dst[u] = isv * BUF + piece * 1024;
+    }
+    auto issue = [&](__amdgpu_buffer_rsrc_t r, int buf) {
+#pragma unroll
+        for (int u = 0; u < NKT; ++u)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(smem + buf * 2 * BUF + kv_dst[u]), 16, (int)kv_off[u], 0, 0, 0);
     };
 
     // Q of the wave's own 32-query block also travels by LDS-DMA into a wave-private 4 KiB image (K-style swizzle), so the
     // loop holds no VGPR-destination global load: hipcc then inserts no vmcnt waits of its own and the counted waits below
     // are the only ones.
     char* sQ = smem + 4 * BUF + wave * 4096;
-    auto issue_q = [&](const T* base) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int row = u * 8 + (lane >> 3);
-            const int c = (lane & 7) ^ ((row >> 1) & 7);
-            const int qi = wave * 32 + row;
-            const int grow = qi < a.T ? qi : a.T - 1;
-            __builtin_amdgcn_global_load_lds((const void*)(base + (int64_t)grow * a.ld_qkv + c * 8), LDS_PTR(sQ + u * 1024), 16, 0, 0);
-        }
+    for (int u = 0; u < 4; ++u) {
+        const int row = u * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int qi = wave * 32 + row;
+        const int grow = qi < a.T ? qi : a.T - 1;
+        q_off[u] = (unsigned)grow * (unsigned)a.ld_qkv * 2u + (unsigned)(c * 16);
+    }
+    auto issue_q = [&](__amdgpu_buffer_rsrc_t r) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(sQ + u * 1024), 16, (int)q_off[u], 0, 0, 0);
     };
     const char* qrd = sQ + (lane & 31) * 128;
     const int qsw = ((lane & 31) >> 1) & 7, qh = lane >> 5;
@@ -398,9 +453,9 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
     if (wave >= 4) __builtin_amdgcn_s_setprio(LECLIP_ATTN_YOUNG_PRIO);
 #endif
     {
-        const T* base = head_base(hd);
-        issue(base, 0);
-        if (active) issue_q(base);
+        const __amdgpu_buffer_rsrc_t r0 = head_rsrc(hd);
+        issue(r0, 0);
+        if (active) issue_q(r0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     for (int it = 0; hd < total_heads; ++it) {
@@ -413,7 +468,7 @@ __global__ __launch_bounds__(512, 2) void attn_heads_kernel(AttnArgs a, int tota
 #ifdef LECLIP_ATTN_SKEW   // A/B builds: waves 4..7 start each head LECLIP_ATTN_SKEW x 64 cycles late, so that a SIMD's two waves are a phase apart
         if (wave >= 4) __builtin_amdgcn_s_sleep(LECLIP_ATTN_SKEW);
 #endif
-        const T* nb = head_base(nxt_c);
+        const __amdgpu_buffer_rsrc_t nb = head_rsrc(nxt_c);
         if (active) {
             v8 q[4];
 #pragma unroll
