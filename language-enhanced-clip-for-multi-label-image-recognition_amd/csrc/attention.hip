@@ -12,9 +12,6 @@
 #include "leclip_common.h"
 #include <stdlib.h>
 
-#ifndef LECLIP_ATTN_V2
-#define LECLIP_ATTN_V2 0
-#endif
 
 namespace {
 
@@ -134,20 +131,10 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                 const int kt = st >> 2, s = st & 3;
                 if (st + KR - 1 < NST) K_ISSUE(st + KR - 1);
                 // DS operations return in order: all but the reads of the younger steps have arrived
-#if LECLIP_ATTN_V2 & 1
-                // (the wait names no register: as an in/out operand of the wait the fragment looked like a fresh vector result to hipcc, which put an
-                //  s_nop - four cycles of the SIMD's issue - in front of each of the 28 MFMAs; the scheduling fence below keeps the MFMA behind the wait)
-                if (st + KR - 1 < NST) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(KR - 1) : "memory");
-                else if (st + 2 < NST) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
-                else if (st + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#else
                 if (st + KR - 1 < NST) asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(kr[st % KR]) : "n"(KR - 1));
                 else if (st + 2 < NST) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(kr[st % KR]));
                 else if (st + 1 < NST) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(kr[st % KR]));
                 else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[st % KR]));
-#endif
                 if (s == 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) sc[kt][r] = 0.f;
@@ -173,9 +160,6 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
         // ---- mask + softmax over keys (rows of S^T); this lane holds keys kt*32 + (r&3) + 8(r>>2) + 4h
         const int klimit = a.causal ? (qrow < a.T - 1 ? qrow : a.T - 1) : a.T - 1;  // last valid key
         float mx = -3.0e38f;
-#if LECLIP_ATTN_V2 & 4
-        float mx_b = -3.0e38f;
-#endif
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             // a key tile needs masking only if it reaches past the last valid key (wave-uniform test): for the
@@ -189,26 +173,15 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                     sc[kt][r] = key <= klimit ? sc[kt][r] : -3.0e38f;
                 }
             }
-#if LECLIP_ATTN_V2 & 4
-#pragma unroll
-            for (int r = 0; r < nr; r += 2) { mx = fmaxf(mx, sc[kt][r]); mx_b = fmaxf(mx_b, sc[kt][r + 1]); }   // two chains (max is exact: any order gives the same value)
-#else
 #pragma unroll
             for (int r = 0; r < nr; ++r) mx = fmaxf(mx, sc[kt][r]);
-#endif
         }
-#if LECLIP_ATTN_V2 & 4
-        mx = fmaxf(mx, mx_b);
-#endif
         mx = lane32_max(mx);   // the query's other lane (v_permlane32_swap: no LDS round trip)
         const float mb = mx * a.scale_log2e;
         // Two keys at a time as a float pair: the scale-and-shift and the row sum issue as packed fp32 instructions (v_pk_fma_f32 /
         // v_pk_add_f32: half the issue slots of that half of the softmax; the sum runs as an even-key and an odd-key partial).
         typedef float f2 __attribute__((ext_vector_type(2)));
         f2 sum2 = {0.f, 0.f};
-#if LECLIP_ATTN_V2 & 2
-        f2 sum2b = {0.f, 0.f};   // second pair of partial sums: four independent chains instead of two
-#endif
         const f2 scl2 = (f2)(a.scale_log2e), nmb2 = (f2)(-mb);
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
@@ -220,27 +193,14 @@ __device__ __forceinline__ void attn_qblock(const AttnArgs& a, const char* sK, c
                     continue;
                 }
                 // v_exp_f32 directly: arguments are <= 0, results below 2^-126 flush to 0 (masked keys: exactly 0)
-#if LECLIP_ATTN_V2 & 8
-                const float x0 = __builtin_fmaf(sc[kt][r], a.scale_log2e, -mb), x1 = __builtin_fmaf(sc[kt][r + 1], a.scale_log2e, -mb);
-                const f2 p = {__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1)};
-#else
                 f2 x = {sc[kt][r], sc[kt][r + 1]};
                 x = __builtin_elementwise_fma(x, scl2, nmb2);
                 const f2 p = {__builtin_amdgcn_exp2f(x.x), __builtin_amdgcn_exp2f(x.y)};
-#endif
                 sc[kt][r] = p.x;
                 sc[kt][r + 1] = p.y;
-#if LECLIP_ATTN_V2 & 2
-                if (r & 2) { sum2b.x += p.x; sum2b.y += p.y; } else { sum2.x += p.x; sum2.y += p.y; }
-#else
                 sum2 += p;
-#endif
             }
-#if LECLIP_ATTN_V2 & 2
-        const float sum = lane32_sum((sum2.x + sum2.y) + (sum2b.x + sum2b.y));
-#else
         const float sum = lane32_sum(sum2.x + sum2.y);
-#endif
         const float inv = 1.0f / sum;
 
         // ---- O^T[d][q] = sum_key V^T[d][key] P^T[key][q]
