@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--image-dtype", default="compute", choices=["compute", "fp32"],
                     help="dtype the synthetic images are resident in when the timed region starts: the tower's compute dtype (default; SURVEY 8d: "
                          "'cast to bf16/fp16 for cfgs 2-5') or fp32 (the engine's patch-extraction kernel then casts inside the step)")
+    ap.add_argument("--no-text-beside", action="store_true",
+                    help="--mode tune A/B: the text tower's forward behind the image tower instead of beside its stream parts (CustomCLIP.text_beside_image)")
     ap.add_argument("--mode", default="score", choices=["score", "tune", "multicrop"],
                     help="score: the headline inference step (default).  tune: BASELINE configs[2], one prompt-tuning step = frozen "
                          "image tower on the batch + text tower forward/backward w.r.t. the 16 context vectors + BCE + SGD")
@@ -522,6 +524,11 @@ def tune(args):
     else:
         images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(tr.device)
     batch = {"img": images, "label": labels}
+    if args.no_text_beside:
+        for root in vars(tr).values():
+            if hasattr(root, "text_beside_image"):
+                root.text_beside_image = False
+        overrides = list(overrides) + ["text_beside_image=False"]
 
     def fence():
         torch.cuda.synchronize()

@@ -151,6 +151,16 @@ class VisionTransformer(nn.Module):
             raise RuntimeError("VisionTransformer.forward needs a HIP device tensor (no CPU fallback on the product path)")
         return self.engine(x.device).forward(x, taps)
 
+    def forward_beside(self, x: torch.Tensor, fn):
+        """(forward(x), fn()): fn's kernels are enqueued on the caller's stream while the tower's stream parts run on theirs, so work that
+        does not depend on the image features (the prompt-tuning step's text tower) overlaps the tower instead of following it."""
+        if not x.is_cuda:
+            raise RuntimeError("VisionTransformer.forward_beside needs a HIP device tensor (no CPU fallback on the product path)")
+        eng = self.engine(x.device)
+        feats = eng.forward(x, beside=fn)
+        res, eng.beside_result = eng.beside_result, None
+        return feats, res
+
     def dense_features(self, x: torch.Tensor) -> torch.Tensor:
         """[B, T, E] fp32 features of every token (class token first): ln_post + proj applied to all rows of the last block."""
         if not x.is_cuda:

@@ -337,6 +337,7 @@ class VisionEngine:
         self.walk = "default"
         # out-proj / c_proj merge their LayerNorm partials inside the launch (384 x 256 kernel; False: a merge launch behind every one of them)
         self.producer_merge = True
+        self.beside_result = None         # what the last forward(..., beside=fn) call's fn returned
 
     def _parts(self, image: torch.Tensor):
         """Row ranges of the stream parts, or None when the batch runs as one piece."""
@@ -345,11 +346,17 @@ class VisionEngine:
         n_cu = torch.cuda.get_device_properties(self.device).multi_processor_count
         return stream_parts(image.shape[0], self.streams, self.split_sizes, self.split_min_batch, self.tokens, self.width, n_cu)
 
-    def _on_streams(self, image: torch.Tensor, fn):
-        """fn(image part) -> tuple of per-image tensors (or None entries); parts run concurrently, results are concatenated."""
+    def _on_streams(self, image: torch.Tensor, fn, beside=None):
+        """fn(image part) -> tuple of per-image tensors (or None entries); parts run concurrently, results are concatenated.
+        ``beside``: a callable enqueued on the CALLER's stream after the parts were forked and before they are joined - work that does
+        not depend on the image tower (the prompt-tuning step's text tower: trainers/caption_distill_double.py CustomCLIP.forward) runs
+        beside it instead of behind it; its result is stored in ``self.beside_result``."""
         bounds = self._parts(image)
         if bounds is None:
-            return fn(image)
+            res = fn(image)
+            if beside is not None:
+                self.beside_result = beside()
+            return res
         cur = torch.cuda.current_stream(self.device)
         side = _part_streams(self.device, len(bounds))
         _note_hw_queues()
@@ -363,6 +370,8 @@ class VisionEngine:
                 if t is not None:
                     t.record_stream(cur)             # allocated on the part's stream, consumed on the caller's
             outs.append(res)
+        if beside is not None:
+            self.beside_result = beside()            # on the caller's stream, which the parts do not use
         for st in side:
             cur.wait_stream(st)
         return tuple(None if outs[0][k] is None else torch.cat([o[k] for o in outs], dim=0) for k in range(len(outs[0])))
@@ -431,16 +440,22 @@ class VisionEngine:
         feat = ops.gather_ln_proj(x, cls_rows, self.ln_post_w, self.ln_post_b, self.proj)     # odd widths (tiny test towers)
         return feat, (ops.l2norm_logits(feat, text_features, scale) if text_features is not None else None)
 
-    def forward(self, image: torch.Tensor, taps: Optional[dict] = None) -> torch.Tensor:
-        """Image features [B, E] fp32 (VisionTransformer.forward)."""
+    def forward(self, image: torch.Tensor, taps: Optional[dict] = None, beside=None) -> torch.Tensor:
+        """Image features [B, E] fp32 (VisionTransformer.forward).  ``beside``: see _on_streams."""
         if image.shape[0] == 0:   # an empty shard (ragged multi-GPU split): nothing to launch
             self._check_image(image)
+            if beside is not None:
+                self.beside_result = beside()
             return torch.empty((0, self.proj.shape[1]), dtype=torch.float32, device=self.device)
 
         def run(part):
             x, batch, cls_rows, stride = self._trunk(part, taps, cls_only=True)
             return (self._tail(x, batch, cls_rows, stride, None, 1.0, True)[0],)
-        return run(image)[0] if taps is not None else self._on_streams(image, run)[0]
+        if taps is not None:
+            if beside is not None:
+                self.beside_result = beside()
+            return run(image)[0]
+        return self._on_streams(image, run, beside)[0]
 
     def dense_features(self, image: torch.Tensor) -> torch.Tensor:
         """[B, T, E] fp32: EVERY token of the last block through ln_post and proj (row 0 = the class token = forward()'s

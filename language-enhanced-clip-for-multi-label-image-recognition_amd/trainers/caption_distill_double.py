@@ -192,6 +192,7 @@ class CustomCLIP(nn.Module):
         self.dtype = clip_model.dtype
         self.model = clip_model
         self._text_cache = None  # (ctx version, features): prompts are constant between updates
+        self.text_beside_image = True   # training: the text tower's forward is enqueued while the image tower's stream parts run (same values)
         # momentum ("EMA") copy of the prompt learner (reference :555-559 `_momentum_update`, :545-553 `copy_params`;
         # cfg.TRAIN.ema / cfg.TRAIN.momentum): m <- momentum * m + (1 - momentum) * p after every training forward
         self.ema = bool(cfg.TRAIN.get("ema", False))
@@ -236,18 +237,28 @@ class CustomCLIP(nn.Module):
         from ..hip import ops
         logit_scale = 4.0  # reference :333-334 (not logit_scale.exp())
         training = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad and self.training
+        text_features = None
         with torch.no_grad():   # both "image" encoders are frozen (reference :762-765)
             if if_test or image is not None:
                 if not training and hasattr(self.image_encoder, "score"):
                     # inference: ln_post + projection + normalise + x4.0 cosine logits are one kernel at the tower's tail
                     return self.image_encoder.score(image, self.class_text_features(), logit_scale), None, None, None
-                image_features = self.image_encoder(image)
+                if training and self.text_beside_image and hasattr(self.image_encoder, "forward_beside"):
+                    # the learnable prompts' text tower does not depend on the images: enqueued beside the frozen image tower's stream parts
+                    def text_side():
+                        with torch.enable_grad():
+                            p = self.prompt_learner()[0]
+                            return self.text_encoder(p, self.tokenized_prompts.to(p.device))
+                    image_features, text_features = self.image_encoder.forward_beside(image, text_side)
+                else:
+                    image_features = self.image_encoder(image)
             else:
                 image_features = self.text_encoder(captions, None, if_embedding=False, if_sequence=False)
         if training:
             from ..hip.autograd import CosineLogitsFunction
-            prompts = self.prompt_learner()[0]
-            text_features = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))
+            if text_features is None:
+                prompts = self.prompt_learner()[0]
+                text_features = self.text_encoder(prompts, self.tokenized_prompts.to(prompts.device))
             self._text_cache = None
             logits = CosineLogitsFunction.apply(image_features, text_features, logit_scale)
             logits_m = None

@@ -286,7 +286,16 @@ def test_cfg3_prompt_tuning_step_at_size(ops, golden_dir):
     l_ref = torch.nn.functional.binary_cross_entropy_with_logits(co.cosine_logits(feats, txt, 4.0), labels)
     l_ref.backward()
     g_ref = ctx.grad.clone()
-    l_hip, g_hip, z_hip, _ = _hip_ctx_grad(arch, sd, ctx0, img, labels, "bce", torch.bfloat16)
+    l_hip, g_hip, z_hip, cc = _hip_ctx_grad(arch, sd, ctx0, img, labels, "bce", torch.bfloat16)
+    # the product enqueues the text tower's forward BESIDE the image tower's stream parts (CustomCLIP.text_beside_image): the same kernels on
+    # the same values in another queue order - logits and gradient must be the bits of the serial order
+    from leclip_amd.trainers.utils import norm_logits_BCEloss
+    assert cc.text_beside_image
+    cc.text_beside_image = False
+    cc.prompt_learner.ctx.grad = None
+    z2 = cc(img.to(DEV), None)[0]
+    norm_logits_BCEloss(z2, labels.to(DEV)).backward()
+    assert torch.equal(z2.detach().cpu(), z_hip) and torch.equal(cc.prompt_learner.ctx.grad.detach().cpu(), g_hip)
     rel = float((g_hip.double() - g_ref.double()).norm() / g_ref.double().norm())
     cos = float(torch.nn.functional.cosine_similarity(g_hip.flatten().double(), g_ref.flatten().double(), dim=0))
     print(f"cfg3 B=512 bf16: loss {l_hip:.5f} vs oracle {float(l_ref):.5f}, grad rel err {rel:.3f}, cos {cos:.5f}")
