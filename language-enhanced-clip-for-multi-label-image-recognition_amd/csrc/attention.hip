@@ -878,7 +878,12 @@ int launch_rows(const AttnArgs& a, int64_t B, hipStream_t s) {
         const int n_cu = leclip_cu_count();
         static bool attr_set[LECLIP_MAX_DEVICES] = {};
         constexpr int LDSB = 4 * 7 * 32 * 128 + 8 * 4096;   // 2 x (K|V) buffers + 8 wave-private Q images
+#ifdef LECLIP_ATTN_GRID_MULT    // A/B builds: more workgroups than CUs
+        const unsigned cap_ = (unsigned)n_cu * LECLIP_ATTN_GRID_MULT;
+        const dim3 g(grid < cap_ ? grid : cap_);
+#else
         const dim3 g(grid < (unsigned)n_cu ? grid : (unsigned)n_cu);
+#endif
         const int live = (a.T - 192 + 7) >> 3;   // 8-key groups of the seventh key tile that hold a valid key (T = 197: one)
 #ifdef LECLIP_ATTN_NO_DEAD_GROUPS   // A/B builds: the round-4 kernel (every group of the last tile computed and masked)
         const int live_k = 4 + 0 * live;

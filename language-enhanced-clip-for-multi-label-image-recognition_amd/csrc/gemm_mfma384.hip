@@ -526,7 +526,12 @@ int launch384_pf(const Gemm384Args& a, int grid, hipStream_t s) {
 template <typename T>
 int launch384(const Gemm384Args& a, hipStream_t s) {
     const int n_cu = leclip_cu_count();
+#ifdef LECLIP_G384_GRID_MULT   // A/B builds: more workgroups than CUs (0: one per tile) - the dispatcher then backfills freed CUs from either stream part's launch
+    const int cap = LECLIP_G384_GRID_MULT > 0 ? n_cu * LECLIP_G384_GRID_MULT : a.tiles_total;
+    const int grid = a.tiles_total < cap ? a.tiles_total : cap;
+#else
     const int grid = a.tiles_total < n_cu ? a.tiles_total : n_cu;
+#endif
     const EpiParams& e = a.epi;
     const bool gelu = e.act == LECLIP_ACT_QUICKGELU, stats = e.stats_out != nullptr, ln = e.ln_stats != nullptr;
     if (e.res) return stats ? launch384_pf<T, 1, 2>(a, grid, s) : launch384_pf<T, 1, 0>(a, grid, s);
