@@ -12,6 +12,7 @@
 // Workgroup ids are remapped so that each XCD (blocks b, b+8, ...) walks a contiguous run of tiles, N fastest:
 // the A row-panel of a tile row is re-read from that XCD's L2, not from HBM.
 #include "leclip_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -264,7 +265,28 @@ int leclip_gemm_dispatch(const void* A, const void* W, int64_t M, int N, int K, 
     // where its rows sit in the batch (round 1 sent the trailing tile rows of a large batch to the 128x128 kernel, whose
     // MFMA shape sums K in a different order - sharded logits then differed from unsharded ones in the last bits).
     // (three families since round 5, all on v_mfma_f32_16x16x32 with ascending K and one epilogue arithmetic: the same bits from each)
-    if (leclip_gemm384_eligible(M, N, K, lda, ldw, epi, ab_dtype)) return leclip_gemm384_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
+    if (leclip_gemm384_eligible(M, N, K, lda, ldw, epi, ab_dtype)) {
+#ifdef LECLIP_GEMM_TAIL_SPLIT   // A/B builds only (make variant VSRC=gemm_mfma DEFS=-DLECLIP_GEMM_TAIL_SPLIT), measured and NOT adopted, profiles/r05_schedule_experiments.txt (9):
+        // the row blocks that fill whole rounds of the persistent launch stay with it, the remaining rows go to a launch of 128 x 128 tiles behind it
+        // (c_fc of a 128-image part: 792 tiles = 3.09 rounds).  Same bits (the families are bit-identical); +1.6 % on the GEMMs of a one-part step,
+        // -0.6 % on the two-part step, whose other part already fills the last round's idle CUs.
+        const int n_cu = leclip_cu_count(), tn = N / 256;
+        const int64_t rb = (M + 383) / 384, tiles = rb * tn, full = tiles / n_cu, rem = tiles % n_cu;
+        if (leclip_gemm_family() < 0 && !epi.stats_out && full >= 1 && rem > 0 && rem * 4 <= n_cu) {
+            const int64_t rb_main = full * n_cu / tn, m_main = rb_main * 384, m_tail = M - m_main;
+            if (rb_main >= 1 && m_tail > 0) {
+                int rc = leclip_gemm384_launch(A, W, m_main, N, K, lda, ldw, epi, ab_dtype, s);
+                if (rc) return rc;
+                EpiParams t = epi;
+                t.out = (char*)epi.out + m_main * epi.ldy * 2;
+                if (epi.res) t.res = (const char*)epi.res + m_main * epi.ldr * 2;
+                if (epi.ln_stats) t.ln_stats = epi.ln_stats + 2 * m_main;
+                return launch_128((const char*)A + m_main * lda * 2, W, m_tail, N, K, lda, ldw, t, ab_dtype, s);
+            }
+        }
+#endif
+        return leclip_gemm384_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
+    }
     if (leclip_gemm256_eligible(M, N, K)) return leclip_gemm256_launch(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
     return launch_128(A, W, M, N, K, lda, ldw, epi, ab_dtype, s);
 }
