@@ -508,9 +508,10 @@ class TextEngine:
         self._ws: Dict[tuple, _Workspace] = {}
 
     def _workspace(self, n: int, t: int) -> _Workspace:
-        key = (n, t)
+        # one workspace per (shape, HIP stream), as in VisionEngine: towers enqueued on different streams must not share activation buffers
+        key = (n, t, torch.cuda.current_stream(self.device).cuda_stream if torch.cuda.is_available() else 0)
         if key not in self._ws:
-            if len(self._ws) > 4:
+            if len(self._ws) > 6:
                 self._ws.clear()
             self._ws[key] = _Workspace(n * t, self.width, self.dtype, self.device)
         return self._ws[key]

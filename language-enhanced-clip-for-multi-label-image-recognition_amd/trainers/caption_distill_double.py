@@ -17,6 +17,7 @@ engines.  Attribute names equal the reference's because they are also the checkp
 """
 from __future__ import annotations
 
+import contextlib
 import os
 import os.path as osp
 import time
@@ -402,13 +403,44 @@ class DenseCLIP(CustomCLIP):
             raise NotImplementedError("TRAIN.IF_LEARN_SCALE / IF_LEARN_spatial_SCALE: learnable scales are not supported in the tuning step")
         logit_scale, tmp = 4.0, float(cfg.TRAIN.spatial_SCALE_text)
         captions = captions.to(self.prompt_learner.ctx.device).long().contiguous()
-        with torch.no_grad():   # the caption encoder is the frozen text tower (:762-765)
+        training = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
+        # The step's three passes through the text tower - the frozen caption encoder, the learnable prompt sets (with gradient) and the momentum
+        # copy's prompt sets - feed the scores only: with `text_beside_image` the first and the third are enqueued on side streams of their own
+        # (the image engine's part streams: no image tower runs in this step) beside the second on the caller's stream, then joined.
+        side = None
+        if self.text_beside_image and captions.is_cuda:
+            from ..hip.engine import _part_streams
+            cur = torch.cuda.current_stream(captions.device)
+            side = _part_streams(captions.device, 2)
+            for st in side:
+                st.wait_stream(cur)
+
+        def on(st):
+            return torch.cuda.stream(st) if side is not None else contextlib.nullcontext()
+
+        def hand_over(*ts):    # allocated on a side stream, consumed on the caller's
+            if side is not None:
+                for t_ in ts:
+                    if t_ is not None:
+                        t_.record_stream(cur)
+
+        with on(side[0] if side else None), torch.no_grad():   # the caption encoder is the frozen text tower (:762-765)
             seq = self.text_encoder(captions, None, if_embedding=False, if_sequence=True).float().contiguous()     # [B, L, E]
             b, l, e = seq.shape
             _, eot_flat = ops.eot_index(captions)
             image_feature_ = ops.gather_rows(seq.view(b * l, e), eot_flat)                                          # :476
-        training = torch.is_grad_enabled() and self.prompt_learner.ctx.requires_grad
+            hand_over(seq, image_feature_)
+        tf_m = tfn_m = tfe_m = None
+        if self.ema:
+            with on(side[1] if side else None), torch.no_grad():
+                self._momentum_update()
+                tf_m, tfn_m, tfe_m = self._text_features_of(self.prompt_learner_m, False)
+                tf_m = tf_m.float().contiguous()
+                hand_over(tf_m, tfn_m, tfe_m)
         text_features, text_features_neg, text_features_evi = self._text_features_of(self.prompt_learner, training)
+        if side is not None:
+            for st in side:
+                cur.wait_stream(st)
         self._text_cache = None
         self.prompt_text_features = None
         logits_ = CosineLogitsFunction.apply(image_feature_, text_features, logit_scale)
@@ -416,9 +448,7 @@ class DenseCLIP(CustomCLIP):
         logits_m_, logits_local_m = None, None
         if self.ema:
             with torch.no_grad():
-                self._momentum_update()
-                tf_m, tfn_m, tfe_m = self._text_features_of(self.prompt_learner_m, False)
-                logits_m_ = ops.l2norm_logits(image_feature_, tf_m.float().contiguous(), logit_scale)
+                logits_m_ = ops.l2norm_logits(image_feature_, tf_m, logit_scale)
                 logits_local_m = LocalPoolFunction.apply(seq, tfn_m, tfe_m, captions, tmp, logit_scale)
         with torch.no_grad():
             image_features = ops.l2norm_rows_(seq.view(b * l, e).clone()).view(b, l, e).permute(1, 0, 2)

@@ -551,11 +551,26 @@ def test_dense_clip_caption_step_at_size(ops, golden_dir, dt_name):
     caps = base[torch.arange(512) % 80].contiguous()
     label = torch.zeros(512, 80)
     label[torch.arange(512), torch.arange(512) % 80] = 1.0
+    m_before = [p.detach().clone() for p in model.prompt_learner_m.parameters()]
     summary = tr.forward_backward({"img": caps.to(DEV), "label": label.to(DEV)})
     assert np.isfinite(summary["loss"]) and np.isfinite(summary["ema_loss"])
     pl = model.prompt_learner
     grads = [p.grad.detach().float().cpu() for p in (pl.ctx, pl.ctx_double, pl.ctx_evidence)]
     assert all(torch.isfinite(gr).all() and float(gr.abs().max()) > 0 for gr in grads)
+    # the product enqueues the step's three text-tower passes side by side on three streams (text_beside_image): one after the other from the
+    # same state (learning rate 0; the momentum copy put back) must give the same loss and the same gradients bit for bit
+    assert model.text_beside_image
+    with torch.no_grad():
+        for p, v in zip(model.prompt_learner_m.parameters(), m_before):
+            p.copy_(v)
+    for p in (pl.ctx, pl.ctx_double, pl.ctx_evidence):
+        p.grad = None
+    model.text_beside_image = False
+    serial = tr.forward_backward({"img": caps.to(DEV), "label": label.to(DEV)})
+    model.text_beside_image = True
+    assert serial["loss"] == summary["loss"] and serial["ema_loss"] == summary["ema_loss"]
+    for gr, p in zip(grads, (pl.ctx, pl.ctx_double, pl.ctx_evidence)):
+        assert torch.equal(gr, p.grad.detach().float().cpu())
     # direction check on a slice (the fp32 oracle of 512 captions through a 12-layer tower is minutes of CPU): same step, 32 captions
     sub = 32
     tr2_summary = None
