@@ -463,9 +463,13 @@ class VisionEngine:
         if image.shape[0] == 0:
             self._check_image(image)
             return torch.empty((0, self.tokens, self.proj.shape[1]), dtype=torch.float32, device=self.device)
-        x, batch, _, _ = self._trunk(image)
-        h = ops.layernorm(x, self.ln_post_w, self.ln_post_b)
-        return ops.gemm(h, self.proj_t_padded(), out_dtype=torch.float32)[:, :self.proj.shape[1]].reshape(batch, self.tokens, -1)
+        w = self.proj_t_padded()          # (built on the caller's stream, before any part is forked)
+
+        def run(part):                    # large batches as stream parts, like forward() / score(): images are independent, same bits
+            x, batch, _, _ = self._trunk(part)
+            h = ops.layernorm(x, self.ln_post_w, self.ln_post_b)
+            return (ops.gemm(h, w, out_dtype=torch.float32)[:, :self.proj.shape[1]].reshape(batch, self.tokens, -1),)
+        return self._on_streams(image, run)[0]
 
     def proj_t_padded(self):
         """proj^T with its row count (E) rounded up to the GEMM kernels' N granularity (zero rows)."""

@@ -757,6 +757,11 @@ def test_full_batch_properties(ops, dt):
         hi = cc(img[128:].contiguous(), if_test=True)[0].clone()
         ragged = torch.cat([cc(img[a:b].contiguous(), if_test=True)[0] for a, b in ((0, 100), (100, 187), (187, 256))])
         one = cc(img[200:201].contiguous(), if_test=True)[0].clone()
+        # every token's feature (the local branch, N4): the batch as stream parts == one image at a time through the small-batch kernels
+        dense = cc.image_encoder.dense_features(img)
+        dense_1 = torch.cat([cc.image_encoder.dense_features(img[i:i + 1].contiguous()) for i in (0, 127, 128, 255)])
+    assert dense.shape == (256, 197, 512) and torch.equal(dense[[0, 127, 128, 255]], dense_1)
+    del dense, dense_1
     assert torch.isfinite(full).all() and torch.equal(full, again)
     assert torch.equal(full[:128], lo) and torch.equal(full[128:], hi)      # 2 equal shards == unsharded, bit for bit
     assert torch.equal(full, ragged)                                        # ragged shards (100 / 87 / 69 images) too
