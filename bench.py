@@ -591,7 +591,8 @@ def tune(args):
                           "config": {"workload": (f"reference's shipped tuning step (TRAIN.MODEL=DenseCLIP): {args.arch}, 3 x 16 learnable context tokens, B={B} captions/GPU, "
                                                   f"double_ranking + EMA KL, SGD") if dense else
                                                  f"BASELINE configs[2]: {args.arch}, 16 learnable context tokens, B={B}/GPU, BCE, SGD",
-                                     "global_batch": world * B, "parallelism": f"dp{world}" + ("+allreduce(ctx grads)" if world > 1 else "")},
+                                     "global_batch": world * B, "parallelism": f"dp{world}" + ("+allreduce(ctx grads)" if world > 1 else ""),
+                                     "independent_towers": "one after the other" if args.no_text_beside else "side by side on HIP streams (text_beside_image)"},
                           "roofline": _tune_roofline(prof), "last_loss": out["loss"], "env_overrides": overrides}))
     if world > 1:
         dist.barrier()

@@ -762,6 +762,15 @@ def test_full_batch_properties(ops, dt):
         dense_1 = torch.cat([cc.image_encoder.dense_features(img[i:i + 1].contiguous()) for i in (0, 127, 128, 255)])
     assert dense.shape == (256, 197, 512) and torch.equal(dense[[0, 127, 128, 255]], dense_1)
     del dense, dense_1
+    # forward_beside: the callable's work is enqueued between the fork and the join of the stream parts (large batch), or simply after the tower
+    # (small batch, empty shard); the features are forward()'s bits and the callable's result comes back with them
+    with torch.no_grad():
+        vis = cc.image_encoder
+        probe = torch.arange(8, device=DEV, dtype=torch.float32)
+        for sl in (slice(0, 256), slice(0, 3), slice(0, 0)):
+            part = img[sl].contiguous()
+            feats, res = vis.forward_beside(part, lambda: probe * 2)
+            assert torch.equal(feats, vis(part)) and torch.equal(res, probe * 2) and vis.engine(DEV).beside_result is None
     assert torch.isfinite(full).all() and torch.equal(full, again)
     assert torch.equal(full[:128], lo) and torch.equal(full[128:], hi)      # 2 equal shards == unsharded, bit for bit
     assert torch.equal(full, ragged)                                        # ragged shards (100 / 87 / 69 images) too
