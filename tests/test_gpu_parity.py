@@ -446,6 +446,12 @@ def test_attention_many_heads(ops, dt, cfg):
     assert torch.equal(y, ops.attention(qkv.to(DEV), b, t, h, False))     # deterministic
     nb = max(1, 1023 // h)                                                 # < 1024 pairs: attn_rows_kernel
     assert nb < b and torch.equal(y[:nb * t], ops.attention(qkv[:nb * t].to(DEV), nb, t, h, False))
+    if cfg in ((86, 197, 12), (86, 201, 12)):                              # the same kernel instances under the causal mask (no model runs them so: kept correct anyway)
+        yc = ops.attention(qkv.to(DEV), b, t, h, True)
+        mask = torch.full((t, t), float("-inf"), device=DEV).triu(1)
+        refc = (torch.softmax(q @ k.transpose(-1, -2) * 0.125 + mask, -1) @ v).transpose(1, 2).reshape(b * t, d)
+        assert float((yc.float() - refc).abs().max()) <= _tol(dt, 2e-5, 4e-3, 2.5e-2)
+        assert torch.equal(yc[:nb * t], ops.attention(qkv[:nb * t].to(DEV), nb, t, h, True))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
