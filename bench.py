@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--image-dtype", default="compute", choices=["compute", "fp32"],
                     help="dtype the synthetic images are resident in when the timed region starts: the tower's compute dtype (default; SURVEY 8d: "
                          "'cast to bf16/fp16 for cfgs 2-5') or fp32 (the engine's patch-extraction kernel then casts inside the step)")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="--mode tune A/B: every step computes its own image features first (no lookahead: Caption_distill_double.pipeline_image_tower = False)")
     ap.add_argument("--no-text-beside", action="store_true",
                     help="--mode tune A/B: the text tower's forward behind the image tower instead of beside its stream parts (CustomCLIP.text_beside_image)")
     ap.add_argument("--mode", default="score", choices=["score", "tune", "multicrop"],
@@ -524,6 +526,10 @@ def tune(args):
     else:
         images = torch.from_numpy(synth.make_images(B, arch.image_resolution, seed=1234, start=rank * B)).to(tr.device)
     batch = {"img": images, "label": labels}
+    if args.no_pipeline or dense:
+        tr.pipeline_image_tower = False
+        if args.no_pipeline:
+            overrides = list(overrides) + ["pipeline_image_tower=False"]
     if args.no_text_beside:
         for root in vars(tr).values():
             if hasattr(root, "text_beside_image"):
@@ -547,15 +553,18 @@ def tune(args):
                     engs.append(mod._engine)
         return engs
 
+    # a loader's lookahead: the trainer computes the NEXT batch's frozen-tower features beside this step's backward (forward_backward, next_batch=);
+    # the synthetic batch is the same tensor every step, and every step still runs one image tower, one text forward / backward and one update
+    nb = None if args.no_pipeline else batch
     for _ in range(args.warmup):
-        out = tr.forward_backward(batch)
+        out = tr.forward_backward(batch, next_batch=nb)
     prof = []
     if args.profile_every > 0:   # the sampled step's one-part workspace, allocated outside the timed region
         engs = vision_engines()
         keep = [(e.streams, e.split_sizes) for e in engs]
         for e in engs:
             e.streams, e.split_sizes = 1, None
-        out = tr.forward_backward(batch)
+        out = tr.forward_backward(batch, next_batch=nb)
         for e, (a_, b_) in zip(engs, keep):
             e.streams, e.split_sizes = a_, b_
     fence()
@@ -568,12 +577,12 @@ def tune(args):
             for e in engs:
                 e.streams, e.split_sizes = 1, None
             ops.set_profile(prof)
-            out = tr.forward_backward(batch)
+            out = tr.forward_backward(batch, next_batch=nb)
             ops.set_profile(None)
             for e, (a_, b_) in zip(engs, keep):
                 e.streams, e.split_sizes = a_, b_
         else:
-            out = tr.forward_backward(batch)
+            out = tr.forward_backward(batch, next_batch=nb)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -592,7 +601,8 @@ def tune(args):
                                                   f"double_ranking + EMA KL, SGD") if dense else
                                                  f"BASELINE configs[2]: {args.arch}, 16 learnable context tokens, B={B}/GPU, BCE, SGD",
                                      "global_batch": world * B, "parallelism": f"dp{world}" + ("+allreduce(ctx grads)" if world > 1 else ""),
-                                     "independent_towers": "one after the other" if args.no_text_beside else "side by side on HIP streams (text_beside_image)"},
+                                     "independent_towers": "one after the other" if args.no_text_beside else "side by side on HIP streams (text_beside_image)",
+                                     "image_tower_lookahead": bool(nb is not None and not dense and not args.no_text_beside)},
                           "roofline": _tune_roofline(prof), "last_loss": out["loss"], "env_overrides": overrides}))
     if world > 1:
         dist.barrier()

@@ -486,6 +486,8 @@ class Caption_distill_double:
         self.max_epoch = int(cfg.OPTIM.MAX_EPOCH)
         self.output_dir = cfg.OUTPUT_DIR
         self._cooc = None
+        self._pipe = None                    # forward_backward(batch, next_batch=...): features handed from one call to the next (_step_pipelined)
+        self.pipeline_image_tower = True     # False: every step computes its own image features first (the reference's order)
         self.build_model()
 
     # ------------------------------------------------------------------------------------------------ construction
@@ -662,8 +664,15 @@ class Caption_distill_double:
         assert self.train_loader_x is not None, "no training loader was given to the trainer"
         self.set_model_mode("train")
         last = {}
-        for self.batch_idx, batch in enumerate(self.train_loader_x):
-            last = self.forward_backward(batch)
+        it = iter(self.train_loader_x)
+        batch = next(it, None)
+        self.batch_idx = -1
+        while batch is not None:
+            nxt = next(it, None)       # one batch of lookahead: its frozen-tower features are computed beside this step's backward (forward_backward)
+            self.batch_idx += 1
+            last = self.forward_backward(batch, next_batch=nxt)
+            batch = nxt
+        self._pipe = None
         self.update_lr()
         if self.rank == 0 and last:
             print(f"epoch [{self.epoch + 1}/{self.max_epoch}] loss {last['loss']:.4f} lr {self.optim.param_groups[0]['lr']:.3e}")
@@ -698,18 +707,29 @@ class Caption_distill_double:
             p.grad = flat[o:o + n].view_as(g).to(g.dtype)
             o += n
 
-    def forward_backward(self, batch):
+    def forward_backward(self, batch, next_batch=None):
         """One prompt-tuning step (reference :789-897, fp32 branch).  ``batch["img"]`` is either tokenised captions
         [B,77] int64 - the reference's texts-as-images feed, ``model(None, captions)`` - or images [B,3,R,R]
         (CoOp-style tuning on the frozen image tower, BASELINE config 3).  Loss: ``ranking_loss(scale_=1, margin_=1)``
         for LOSSFUNC == "double_ranking" (:806-808), BCE-with-logits for "bce" (trainers/utils.py:21-23).  Under
-        WORLD_SIZE > 1 the batch is this rank's shard and the gradients are averaged over ranks before the step."""
+        WORLD_SIZE > 1 the batch is this rank's shard and the gradients are averaged over ranks before the step.
+
+        ``next_batch`` (image batches on CustomCLIP; run_epoch passes the loader's next item): the frozen image tower does not depend on the
+        prompts, so the NEXT batch's image features are computed on the tower's stream parts while this step's backward, all-reduce, optimizer
+        step and the next step's text-tower forward run on the caller's stream (`_step_pipelined`) - the same kernels on the same values as
+        the one-batch-at-a-time order, a step no longer than the longer of the two."""
         from .utils import norm_logits_BCEloss, ranking_loss
         name = self.get_model_names()[0]
         model = getattr(self, f"model_{name}")
         optim = self._optims[name]
         model.train()
         inp, label = self.parse_batch_train(batch)
+        if ((next_batch is not None or self._pipe is not None) and self.pipeline_image_tower and type(model) is CustomCLIP and not model.ema
+                and inp.is_cuda and inp.dtype not in (torch.int64, torch.int32) and model.text_beside_image
+                and model.prompt_learner.ctx.requires_grad and self.cfg.TRAIN.LOSSFUNC in ("double_ranking", "bce")
+                and hasattr(model.image_encoder, "forward_beside")):
+            return self._step_pipelined(model, optim, inp, label, next_batch)
+        self._pipe = None
         output_local = output_m = output_local_m = None
         if isinstance(model, DenseCLIP):
             # the reference's step as shipped (TRAIN.MODEL = "DenseCLIP", train_caption.py:110): `model(None, captions)` (:802)
@@ -755,6 +775,48 @@ class Caption_distill_double:
             summary = {f"loss_{lf}": loss.item()}
         summary["loss"] = loss.item()
         return summary
+
+    def _step_pipelined(self, model, optim, inp, label, next_batch):
+        """forward_backward with one batch of lookahead (CustomCLIP on image batches).  State between calls: the image features of the batch
+        about to be stepped on and the text features (with their autograd graph) of the current prompts, both produced during the previous call."""
+        from ..hip.autograd import CosineLogitsFunction
+        from .utils import norm_logits_BCEloss, ranking_loss
+
+        def key_of(t):
+            return (t.data_ptr(), tuple(t.shape), t._version)
+
+        def text_forward():
+            with torch.enable_grad():
+                p = model.prompt_learner()[0]
+                return model.text_encoder(p, model.tokenized_prompts.to(p.device))
+
+        st = self._pipe
+        if st is None or st["key"] != key_of(inp) or st["ctx_version"] != model.prompt_learner.ctx._version:
+            feats, text = model.image_encoder.forward_beside(inp, text_forward)        # first step (or a batch nobody announced): nothing to reuse
+        else:
+            feats, text = st["feats"], st["text"]
+        self._pipe = None
+        output = CosineLogitsFunction.apply(feats, text, 4.0)                          # reference :333-334: scale 4, not logit_scale.exp()
+        lf = self.cfg.TRAIN.LOSSFUNC
+        loss = ranking_loss(output, label, scale_=1.0, margin_=1) if lf == "double_ranking" else norm_logits_BCEloss(output, label.float())
+        optim.zero_grad()
+
+        def rest_of_step():      # on the caller's stream, beside the next batch's image tower
+            loss.backward()
+            self._allreduce_grads([p for g in optim.param_groups for p in g["params"]])
+            optim.step()
+            model._text_cache = None
+            return text_forward() if next_batch is not None else None                  # the NEXT step's text features, from the updated prompts
+        if next_batch is not None:
+            nxt, _ = self.parse_batch_train(next_batch)
+            feats_n, text_n = model.image_encoder.forward_beside(nxt, rest_of_step)
+            self._pipe = {"key": key_of(nxt), "ctx_version": model.prompt_learner.ctx._version, "feats": feats_n, "text": text_n}
+        else:
+            rest_of_step()                                                             # the loader's last batch: nothing to look ahead to
+        val = loss.item()
+        if val != val or val in (float("inf"), float("-inf")):
+            raise FloatingPointError("Loss is infinite or NaN!")   # dassl/engine/trainer.py:224-226 (found one step late: the update has been made)
+        return {f"loss_{lf}": val, "loss": val}
 
     # ------------------------------------------------------------------------------------------------------- testing
     def cooccurrence_matrix(self):

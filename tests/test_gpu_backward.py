@@ -223,6 +223,44 @@ def test_trainer_forward_backward_reduces_loss(ops, golden_dir):
     assert out.shape == (2, 80)
 
 
+@pytest.mark.parametrize("backbone,size,prec,n", [("tiny", 32, "fp32", 6), ("ViT-B/16", 224, "fp16", 160)])
+def test_pipelined_tuning_steps_equal_the_serial_order(ops, backbone, size, prec, n):
+    """forward_backward(batch, next_batch=...) computes the NEXT batch's frozen-tower features beside this step's backward, all-reduce and
+    update, and hands them to the next call (Caption_distill_double._step_pipelined; run_epoch passes the loader's lookahead).  Four steps over
+    three different image batches with a real learning rate - one trainer pipelined, one in the reference's order, the same starting prompts -
+    must give the same losses and the same prompts bit for bit; a batch that was not announced, and the last batch, take the fallbacks.
+    (ViT-B/16 with 160 images: the tower runs as stream parts, so the rest of the step really is enqueued beside it.)"""
+    from leclip_amd.config import get_cfg_default
+    from leclip_amd.registry import build_trainer
+    torch.manual_seed(0)
+
+    def make():
+        cfg = get_cfg_default()
+        cfg.merge_from_list(["MODEL.BACKBONE.NAME", backbone, "MODEL.BACKBONE.PATH", "synthetic:1:cond", "INPUT.SIZE", f"({size}, {size})",
+                             "TRAINER.Caption.PREC", prec, "OPTIM.LR", "0.002", "OPTIM.WARMUP_EPOCH", "0", "TRAIN.LOSSFUNC", "bce"])
+        return build_trainer(cfg)
+    a, b = make(), make()
+    with torch.no_grad():
+        b.model_default.prompt_learner.ctx.copy_(a.model_default.prompt_learner.ctx)
+    b.pipeline_image_tower = False
+    batches = []
+    for k in range(3):
+        img = torch.from_numpy(synth.make_images(n, size, seed=40 + k))
+        lab = torch.from_numpy((synth.uniform(50 + k, "lab", (n, 80), 0, 1) < 0.06).astype(np.float32))
+        batches.append({"img": img.to(DEV), "label": lab.to(DEV)})
+    order = [0, 1, 2, 1]
+    la, lb = [], []
+    for i, k in enumerate(order):
+        nxt = batches[order[i + 1]] if i + 1 < len(order) else None
+        if i == 2:
+            nxt = batches[0]          # announce one batch, then step on another (next call): the stale features must not be used
+        la.append(a.forward_backward(batches[k], next_batch=nxt)["loss"])
+        lb.append(b.forward_backward(batches[k])["loss"])
+    assert la == lb, (la, lb)
+    assert torch.equal(a.model_default.prompt_learner.ctx.detach(), b.model_default.prompt_learner.ctx.detach())
+    assert a._pipe is None and all(np.isfinite(la)) and len(set(la)) == len(la)       # (the last call had nothing to look ahead to; the losses moved)
+
+
 def test_trainer_momentum_copy_follows_the_prompts(ops, golden_dir):
     """cfg.TRAIN.ema: after every training forward the momentum prompts move toward the tuned prompts and their
     no-grad scores come back in the fourth output slot (reference CDD.py:516-523, 555-559)."""
