@@ -791,7 +791,7 @@ class Caption_distill_double:
                 return model.text_encoder(p, model.tokenized_prompts.to(p.device))
 
         st = self._pipe
-        if st is None or st["key"] != key_of(inp) or st["ctx_version"] != model.prompt_learner.ctx._version:
+        if st is None or st["key"] != key_of(inp) or st["ctx_version"] != key_of(model.prompt_learner.ctx):
             feats, text = model.image_encoder.forward_beside(inp, text_forward)        # first step (or a batch nobody announced): nothing to reuse
         else:
             feats, text = st["feats"], st["text"]
@@ -810,7 +810,7 @@ class Caption_distill_double:
         if next_batch is not None:
             nxt, _ = self.parse_batch_train(next_batch)
             feats_n, text_n = model.image_encoder.forward_beside(nxt, rest_of_step)
-            self._pipe = {"key": key_of(nxt), "ctx_version": model.prompt_learner.ctx._version, "feats": feats_n, "text": text_n}
+            self._pipe = {"key": key_of(nxt), "ctx_version": key_of(model.prompt_learner.ctx), "feats": feats_n, "text": text_n}
         else:
             rest_of_step()                                                             # the loader's last batch: nothing to look ahead to
         val = loss.item()
